@@ -1,0 +1,372 @@
+// crt_api.cpp -- the C ABI of include/crt_hip.h: context, scene upload, BVH, camera, launches.
+// Product code; never touches oracle/.  Fails with an error code when no HIP device or no
+// gfx950 code object is usable -- there is no CPU fallback.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "crt_host.h"
+#include "crt_launch.h"
+
+struct crt_context {
+    int device = 0;
+    uint64_t seed = 1;
+    std::string err;
+    // host copies
+    int n = 0, m = 0;
+    std::vector<float> center, motion, radius;
+    std::vector<crt_bvh_node> nodes;
+    int num_leaves = 0;
+    crt_camera cam{};
+    bool have_cam = false;
+    // device
+    void* d_pairs = nullptr;
+    void* d_spheres = nullptr;
+    void* d_mats = nullptr;
+    float* d_fb = nullptr;
+    size_t fb_floats = 0;
+    unsigned long long* d_counters = nullptr;
+    int *d_px = nullptr, *d_py = nullptr, *d_smp = nullptr, *d_seg = nullptr;
+    float *d_ray7 = nullptr, *d_rgb = nullptr;
+    int dbg_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool launched = false;
+    double wall_seconds = 0;
+    // tuning
+    int block = 512;
+    int chunks = 0;  // 0 = auto
+    bool count_stats = false;
+    size_t lds_limit = 64 * 1024;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(crt_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define CRT_HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+int pick_chunks(const crt_context* ctx, int nsamples) {
+    const int nw = ctx->block / 64;
+    if (ctx->chunks > 0) return ctx->chunks < nw ? ctx->chunks : nw;
+    int c = nw;
+    while (c > 1 && (nsamples + c - 1) / c < 8) c >>= 1;  // keep >= 8 samples per chunk
+    return c;
+}
+
+float as_float(int32_t bits) { float f; memcpy(&f, &bits, 4); return f; }
+
+}  // namespace
+
+extern "C" {
+
+const char* crt_last_error(const crt_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int crt_create(int32_t device, uint64_t seed, crt_context** out) {
+    if (!out) return fail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, CRT_ERR_NO_DEVICE, std::string("crt_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device < 0 || device >= count) return fail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_create: device index out of range");
+    CRT_HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CRT_HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CRT_ERR_NO_DEVICE, std::string("crt_create: device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    crt_context* ctx = new crt_context;
+    ctx->device = device;
+    ctx->seed = seed;
+    if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 1024) ctx->block = v; }
+    if (hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
+    }
+    *out = ctx;
+    return CRT_OK;
+}
+
+int crt_destroy(crt_context* ctx) {
+    if (!ctx) return CRT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {ctx->d_pairs, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_counters, ctx->d_px, ctx->d_py,
+                    ctx->d_smp, ctx->d_seg, ctx->d_ray7, ctx->d_rgb};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+    return CRT_OK;
+}
+
+int crt_set_seed(crt_context* ctx, uint64_t seed) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    ctx->seed = seed;
+    return CRT_OK;
+}
+
+int crt_set_chunks(crt_context* ctx, int32_t chunks) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_set_chunks: chunks must be 0, 1, 2, 4, 8 or 16");
+    ctx->chunks = chunks;
+    return CRT_OK;
+}
+
+int crt_set_count_stats(crt_context* ctx, int32_t enable) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    ctx->count_stats = enable != 0;
+    return CRT_OK;
+}
+
+int32_t crt_chunk_spp(const crt_context* ctx, int32_t nsamples) {
+    if (!ctx || nsamples < 1) return 0;
+    const int c = pick_chunks(ctx, nsamples);
+    return (nsamples + c - 1) / c;
+}
+
+int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const float* motion, const float* radius,
+                     const int32_t* mat_id, int32_t m, const int32_t* mat_type, const float* mat_albedo,
+                     const float* mat_param) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (n < 1 || m < 1 || !center || !motion || !radius || !mat_id || !mat_type || !mat_albedo || !mat_param)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: empty scene or NULL array");
+    if (m > CRT_MAT_ID_MASK) return fail(ctx, CRT_ERR_TOO_LARGE, "crt_upload_scene: too many materials");
+    for (int i = 0; i < m; ++i)
+        if (mat_type[i] < 0 || mat_type[i] > 2) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: unknown material type");
+    for (int i = 0; i < n; ++i)
+        if (mat_id[i] < 0 || mat_id[i] >= m) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: mat_id out of range");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    std::vector<float> sph(8 * size_t(n)), mats(4 * size_t(m));
+    for (int i = 0; i < n; ++i) {
+        float* s = &sph[8 * size_t(i)];
+        s[0] = center[3 * i]; s[1] = center[3 * i + 1]; s[2] = center[3 * i + 2];
+        s[3] = fmaxf(0.0f, radius[i]);  // sphere.h:11 radius(fmaxf(0, radius))
+        s[4] = motion[3 * i]; s[5] = motion[3 * i + 1]; s[6] = motion[3 * i + 2];
+        s[7] = as_float(int32_t(uint32_t(mat_id[i]) | (uint32_t(mat_type[mat_id[i]]) << CRT_MAT_TYPE_SHIFT)));
+    }
+    for (int i = 0; i < m; ++i) {
+        float* q = &mats[4 * size_t(i)];
+        if (mat_type[i] == CRT_DIELECTRIC) {
+            q[0] = mat_param[i];
+            q[1] = float(1.0 / double(mat_param[i]));  // material.h:69 (1.0/refraction_index)
+            q[2] = q[3] = 0.0f;
+        } else {
+            q[0] = mat_albedo[3 * i]; q[1] = mat_albedo[3 * i + 1]; q[2] = mat_albedo[3 * i + 2];
+            q[3] = mat_type[i] == CRT_METAL ? (mat_param[i] < 1.0f ? mat_param[i] : 1.0f) : 0.0f;  // material.h:46
+        }
+    }
+    if (ctx->d_spheres) { (void)hipFree(ctx->d_spheres); ctx->d_spheres = nullptr; }
+    if (ctx->d_mats) { (void)hipFree(ctx->d_mats); ctx->d_mats = nullptr; }
+    if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+    ctx->nodes.clear(); ctx->num_leaves = 0;
+    CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_spheres, sph.size() * sizeof(float)));
+    CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_mats, mats.size() * sizeof(float)));
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_spheres, sph.data(), sph.size() * sizeof(float), hipMemcpyHostToDevice));
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->n = n; ctx->m = m;
+    ctx->center.assign(center, center + 3 * size_t(n));
+    ctx->motion.assign(motion, motion + 3 * size_t(n));
+    ctx->radius.assign(radius, radius + size_t(n));
+    return CRT_OK;
+}
+
+int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "crt_build_bvh: no scene uploaded");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    const int L = 1 << crt::bvh_depth(ctx->n);
+    ctx->nodes.resize(2 * size_t(L) - 1);
+    crt::bvh_build(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), axis_seed, ctx->nodes.data());
+    // child-pair records (crt_device.h): record k (1-based heap) holds nodes 2k-1, 2k (0-based)
+    std::vector<float> pairs(16 * size_t(L), 0.0f);
+    auto tag_of = [&](const crt_bvh_node& nd) -> int32_t {
+        if (nd.xmin > nd.xmax) return CRT_TAG_EMPTY;
+        return nd.loc_for_leaf >= 0 ? nd.loc_for_leaf : CRT_TAG_INTERNAL;
+    };
+    if (L == 1) {
+        pairs[12] = as_float(tag_of(ctx->nodes[0]));  // the root is the only leaf
+        pairs[13] = as_float(CRT_TAG_EMPTY);
+    }
+    for (int k = 1; k < L; ++k) {
+        const crt_bvh_node &l = ctx->nodes[2 * size_t(k) - 1], &r = ctx->nodes[2 * size_t(k)];
+        float* q = &pairs[16 * size_t(k)];
+        q[0] = l.xmin; q[1] = l.xmax; q[2] = r.xmin; q[3] = r.xmax;
+        q[4] = l.ymin; q[5] = l.ymax; q[6] = r.ymin; q[7] = r.ymax;
+        q[8] = l.zmin; q[9] = l.zmax; q[10] = r.zmin; q[11] = r.zmax;
+        q[12] = as_float(tag_of(l)); q[13] = as_float(tag_of(r));
+    }
+    if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+    CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, pairs.size() * sizeof(float)));
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->num_leaves = L;
+    if (num_nodes_out) *num_nodes_out = int32_t(ctx->nodes.size());
+    return CRT_OK;
+}
+
+int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity) {
+    if (!ctx || !out) return CRT_ERR_INVALID_ARGUMENT;
+    if (ctx->nodes.empty()) return CRT_ERR_STATE;
+    if (size_t(capacity) < ctx->nodes.size()) return CRT_ERR_TOO_LARGE;
+    memcpy(out, ctx->nodes.data(), ctx->nodes.size() * sizeof(crt_bvh_node));
+    return CRT_OK;
+}
+
+int crt_set_camera(crt_context* ctx, const crt_camera* cam) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!cam || cam->image_width < 1 || cam->image_height < 1)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_set_camera: bad camera");
+    if (int64_t(cam->image_width) * cam->image_height > (1ll << 31) - 1)
+        return fail(ctx, CRT_ERR_TOO_LARGE, "crt_set_camera: more than 2^31-1 pixels");
+    ctx->cam = *cam;
+    ctx->have_cam = true;
+    return CRT_OK;
+}
+
+static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth, float* d_sums, crt_render_args& a) {
+    if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "render: no camera set");
+    if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "render: no scene uploaded");
+    if (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: unknown world kind");
+    if (world == CRT_WORLD_BVH && !ctx->d_pairs) return fail(ctx, CRT_ERR_STATE, "render: CRT_WORLD_BVH needs crt_build_bvh first");
+    if (ns < 1 || s0 < 0 || max_depth < 1) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: nsamples, sample_offset or max_depth out of range");
+    const crt_camera& c = ctx->cam;
+    memcpy(a.cam.center, c.center, 12); memcpy(a.cam.p00, c.pixel00_loc, 12);
+    memcpy(a.cam.du, c.pixel_delta_u, 12); memcpy(a.cam.dv, c.pixel_delta_v, 12);
+    memcpy(a.cam.ddu, c.defocus_disk_u, 12); memcpy(a.cam.ddv, c.defocus_disk_v, 12);
+    a.cam.defocus_angle = c.defocus_angle;
+    a.cam.width = c.image_width; a.cam.height = c.image_height;
+    a.pairs = ctx->d_pairs; a.spheres = ctx->d_spheres; a.mats = ctx->d_mats;
+    a.num_leaves = ctx->num_leaves; a.n = ctx->n; a.m = ctx->m;
+    a.key0 = uint32_t(ctx->seed); a.key1 = uint32_t(ctx->seed >> 32);
+    a.s0 = s0; a.ns = ns;
+    a.chunks = pick_chunks(ctx, ns);
+    a.chunk_spp = (ns + a.chunks - 1) / a.chunks;
+    a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
+    a.max_depth = max_depth;
+    a.sums = d_sums;
+    a.counters = ctx->d_counters;
+    return CRT_OK;
+}
+
+int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
+                          int32_t max_depth, float* d_sums, void* stream_) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_accumulate: d_sums is NULL");
+    crt_render_args a;
+    memset(&a, 0, sizeof a);
+    if (int rc = fill_args(ctx, world, sample_offset, nsamples, max_depth, d_sums, a)) return rc;
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nw = ctx->block / 64;
+    const int tiles_per_block = nw / a.chunks;
+    const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
+    const int grid = int((tiles + tiles_per_block - 1) / tiles_per_block);
+    size_t scene_bytes = 32 * size_t(ctx->n) + 16 * size_t(ctx->m) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
+    const bool in_lds = scene_bytes <= ctx->lds_limit;
+    size_t lds = in_lds ? scene_bytes : 0;
+    const size_t red = a.chunks > 1 ? size_t(nw) * 3 * 64 * sizeof(float) : 0;
+    if (lds < red) lds = red;
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, stream));
+    CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, ctx->block, grid, lds, stream));
+    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, stream));
+    ctx->launched = true;
+    return CRT_OK;
+}
+
+int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
+    if (!ctx || !stats) return CRT_ERR_INVALID_ARGUMENT;
+    memset(stats, 0, sizeof *stats);
+    if (!ctx->launched) return fail(ctx, CRT_ERR_STATE, "crt_get_stats: nothing launched yet");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    float ms = 0;
+    CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    unsigned long long c[4];
+    CRT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    stats->kernel_seconds = ms * 1e-3;
+    stats->wall_seconds = ctx->wall_seconds;
+    stats->rays = c[0]; stats->samples = c[1]; stats->pair_visits = c[2]; stats->sphere_tests = c[3];
+    return CRT_OK;
+}
+
+int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth, float* fb_host,
+               crt_render_stats* stats) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!fb_host) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render: fb_host is NULL");
+    if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "crt_render: no camera set");
+    const auto t0 = std::chrono::steady_clock::now();
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t floats = 3 * size_t(ctx->cam.image_width) * size_t(ctx->cam.image_height);
+    if (ctx->fb_floats < floats) {
+        if (ctx->d_fb) { (void)hipFree(ctx->d_fb); ctx->d_fb = nullptr; ctx->fb_floats = 0; }
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_fb, floats * sizeof(float)));
+        ctx->fb_floats = floats;
+    }
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb, 0, floats * sizeof(float), nullptr));
+    if (int rc = crt_render_accumulate(ctx, world, sample_offset, spp, max_depth, ctx->d_fb, nullptr)) return rc;
+    CRT_HIP_TRY(ctx, hipMemcpy(fb_host, ctx->d_fb, floats * sizeof(float), hipMemcpyDeviceToHost));
+    const float scale = float(1.0 / double(spp));  // camera.h:76 pixel_samples_scale
+    for (size_t i = 0; i < floats; ++i) fb_host[i] = fb_host[i] * scale;
+    ctx->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) return crt_get_stats(ctx, stats);
+    return CRT_OK;
+}
+
+int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int32_t* px, const int32_t* py,
+                      const int32_t* sample, int32_t max_depth, float* ray7_out, float* rgb_out, int32_t* segments_out) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (count < 1 || !px || !py || !sample || !ray7_out || !rgb_out || !segments_out)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: bad arguments");
+    crt_render_args a;
+    memset(&a, 0, sizeof a);
+    if (int rc = fill_args(ctx, world, 0, 1, max_depth, nullptr, a)) return rc;
+    for (int i = 0; i < count; ++i)
+        if (px[i] < 0 || px[i] >= ctx->cam.image_width || py[i] < 0 || py[i] >= ctx->cam.image_height || sample[i] < 0)
+            return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: pixel or sample out of range");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->dbg_cap < count) {
+        void** bufs[] = {(void**)&ctx->d_px, (void**)&ctx->d_py, (void**)&ctx->d_smp, (void**)&ctx->d_seg, (void**)&ctx->d_ray7, (void**)&ctx->d_rgb};
+        for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+        ctx->dbg_cap = 0;
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_px, size_t(count) * 4));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_py, size_t(count) * 4));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_smp, size_t(count) * 4));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seg, size_t(count) * 4));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ray7, size_t(count) * 28));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rgb, size_t(count) * 12));
+        ctx->dbg_cap = count;
+    }
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_px, px, size_t(count) * 4, hipMemcpyHostToDevice));
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_py, py, size_t(count) * 4, hipMemcpyHostToDevice));
+    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_smp, sample, size_t(count) * 4, hipMemcpyHostToDevice));
+    CRT_HIP_TRY(ctx, crt_launch_trace_samples(a, world, count, ctx->d_px, ctx->d_py, ctx->d_smp, ctx->d_ray7, ctx->d_rgb, ctx->d_seg, nullptr));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    CRT_HIP_TRY(ctx, hipMemcpy(ray7_out, ctx->d_ray7, size_t(count) * 28, hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(rgb_out, ctx->d_rgb, size_t(count) * 12, hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(segments_out, ctx->d_seg, size_t(count) * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+}  // extern "C"

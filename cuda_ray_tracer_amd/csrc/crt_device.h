@@ -1,0 +1,55 @@
+// crt_device.h -- device-side data layout shared by the kernels and the host launcher.
+//
+// HBM layout (all arrays 16-byte aligned, read-only during a render):
+//
+//  pairs   : float4[4 * L]   L = number of leaves of the complete tree (power of two).
+//            Record k (1 <= k < L, 64 B) holds the TWO children of heap node k
+//            (1-based heap: children of k are 2k and 2k+1; the reference's 0-based
+//            node i is k = i+1, bvh.h:87-95):
+//              q0 = { L.xmin, L.xmax, R.xmin, R.xmax }
+//              q1 = { L.ymin, L.ymax, R.ymin, R.ymax }
+//              q2 = { L.zmin, L.zmax, R.zmin, R.zmax }
+//              q3 = { tagL, tagR, -, - } (int bits)  tag >= 0: sphere index of a leaf,
+//                   CRT_TAG_INTERNAL: internal node, CRT_TAG_EMPTY: padding / all-padding subtree.
+//            Child indices are implicit, so the traversal keeps no node stack: a node index
+//            and one 32-bit "right sibling pending" mask replace the reference's
+//            bvh_node* stack[32] (helper_experimental.h:11-13).
+//  spheres : float4[2 * n]   { cx, cy, cz, radius }, { mx, my, mz, mat_id | type << 28 }
+//            (sphere.h:38-41: center ray origin, direction, radius, mat_ptr)
+//  mats    : float4[m]       lambertian/metal { r, g, b, fuzz }; dielectric { ior, 1/ior, -, - }
+//  sums    : float[3 * W * H] un-normalised RGB sums, row-major (helper.h:139-141 layout)
+#ifndef CRT_DEVICE_H
+#define CRT_DEVICE_H
+
+#include <stdint.h>
+
+#define CRT_TAG_INTERNAL (-1)
+#define CRT_TAG_EMPTY (-2)
+#define CRT_MAT_TYPE_SHIFT 28
+#define CRT_MAT_ID_MASK 0x0fffffff
+
+struct crt_dev_camera {
+    float center[3], p00[3], du[3], dv[3], ddu[3], ddv[3];
+    float defocus_angle;
+    int width, height;
+};
+
+struct crt_render_args {
+    crt_dev_camera cam;
+    const void* pairs;
+    const void* spheres;
+    const void* mats;
+    int num_leaves;  // L
+    int n;           // spheres
+    int m;           // materials
+    uint32_t key0, key1;
+    int s0, ns;      // first sample index, sample count of this call
+    int chunk_spp;   // samples per chunk
+    int chunks;      // chunks per workgroup (waves of one tile)
+    int tiles_x, tiles_y;
+    int max_depth;
+    float* sums;
+    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests
+};
+
+#endif

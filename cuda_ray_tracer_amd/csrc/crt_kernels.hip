@@ -1,0 +1,497 @@
+// crt_kernels.hip -- the hot path, hand-written for gfx950 (CDNA4, wave64).
+//
+// One lane owns one pixel of an 8x8 tile and walks that pixel's samples of one chunk in
+// order; when a path ends the lane regenerates its next sample inside the same loop
+// iteration, so a wave never idles on its longest path.  A workgroup is NW waves =
+// (tiles per block) x (chunks per tile); chunk sums meet in LDS and are added to the
+// framebuffer in chunk order -- no atomics, the result is deterministic.
+//
+// The scene (child-pair BVH records, spheres, materials; <= 64 KB for the reference's
+// random-spheres scene) is staged into LDS once per workgroup; scenes that do not fit
+// are read from HBM through L1/L2.
+//
+// Arithmetic contract: every fp32 operation is one IEEE rounding in the order the
+// reference's C++ expressions give (no contraction, correctly rounded / and sqrt), so a
+// path is bit-identical to oracle/rt_oracle.cpp for the same Philox stream.
+// References: render_with_cuda.h:6-56,116-168; helper_experimental.h:1-78; sphere.h:44-73;
+// material.h:22-98; vec3.h:130-160; aabb.h:48-62.
+#include <hip/hip_runtime.h>
+
+#include "crt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ v3 operator*(float t, v3 a) { return mk(t * a.x, t * a.y, t * a.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// vec3.h:114-116,130-132: v / t == (1/t) * v
+__device__ __forceinline__ v3 unit(v3 a) { return (1.0f / sqrtf(len2(a))) * a; }
+
+// ---- Philox4x32-10, counter = (event, sample, pixel, 0), key = seed -------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long m1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)m1; c2 = n2; c3 = (uint32_t)m0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// (0,1], rocRAND's mapping; v * 2^-32 is exact, so the sum is one rounding
+__device__ __forceinline__ float u01(uint32_t v) { return 2.3283064e-10f + ((float)v * 2.3283064e-10f); }
+
+struct stream {
+    uint32_t k0, k1, pixel, sample, event;
+    __device__ __forceinline__ float4 next_block() {
+        const uint4 r = philox4x32_10(event, sample, pixel, 0u, k0, k1);
+        ++event;
+        return make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+    }
+};
+
+// random_float(state, -1, 1) = min + (max - min) * (1 - u), rtweekend.h:25-28
+__device__ __forceinline__ float rf11(float u) { return -1.0f + 2.0f * (1.0f - u); }
+
+// vec3.h:145-152 -- one Philox block per attempt
+__device__ __forceinline__ v3 random_unit_vector(stream& rs) {
+    for (;;) {
+        const float4 b = rs.next_block();
+        const v3 p = mk(rf11(b.x), rf11(b.y), rf11(b.z));
+        const float lensq = len2(p);
+        if (0.0f < lensq && lensq <= 1.0f) return (1.0f / sqrtf(lensq)) * p;
+    }
+}
+
+// vec3.h:154-160 -- one block carries two attempts
+__device__ __forceinline__ void random_in_unit_disk(stream& rs, float& dx, float& dy) {
+    for (;;) {
+        const float4 b = rs.next_block();
+        float x = rf11(b.x), y = rf11(b.y);
+        if (x * x + y * y + 0.0f * 0.0f < 1.0f) { dx = x; dy = y; return; }
+        x = rf11(b.z); y = rf11(b.w);
+        if (x * x + y * y + 0.0f * 0.0f < 1.0f) { dx = x; dy = y; return; }
+    }
+}
+
+struct ray_t { v3 o, d; float tm; };
+
+// render_with_cuda.h:6-29
+__device__ __forceinline__ ray_t get_ray(stream& rs, const crt_dev_camera& cam, int pixel_x, int pixel_y) {
+    const float4 b = rs.next_block();
+    const float x_offset = b.x - 0.5f;
+    const float y_offset = b.y - 0.5f;
+    const v3 pixel_sample = (ld3(cam.p00) + (((float)pixel_x + x_offset) * ld3(cam.du))) +
+                            (((float)pixel_y + y_offset) * ld3(cam.dv));
+    float dx, dy;
+    random_in_unit_disk(rs, dx, dy);  // always sampled
+    const v3 p_in_disk = (ld3(cam.center) + dx * ld3(cam.ddu)) + dy * ld3(cam.ddv);
+    ray_t r;
+    r.o = (cam.defocus_angle <= 0.0f) ? ld3(cam.center) : p_in_disk;
+    r.d = pixel_sample - r.o;
+    r.tm = 1.0f - b.z;
+    return r;
+}
+
+struct sphere_rec { v3 c, mo; float radius; int mat; };
+
+template <bool IN_LDS>
+__device__ __forceinline__ sphere_rec load_sphere(const float4* spheres, int i) {
+    const float4 a = spheres[2 * i], b = spheres[2 * i + 1];
+    sphere_rec s;
+    s.c = mk(a.x, a.y, a.z); s.radius = a.w;
+    s.mo = mk(b.x, b.y, b.z); s.mat = __float_as_int(b.w);
+    return s;
+}
+
+// sphere.h:44-66: returns the accepted root or a negative value (roots are > tmin = 0.001)
+__device__ __forceinline__ float sphere_root(const sphere_rec& s, const ray_t& r, float a, float tmin, float tmax) {
+    const v3 cc = s.c + r.tm * s.mo;  // center.at(r.time())
+    const v3 oc = cc - r.o;
+    const float h = dot(r.d, oc);
+    const float c = len2(oc) - s.radius * s.radius;
+    const float disc = h * h - a * c;
+    if (disc < 0.0f) return -1.0f;
+    const float sq = sqrtf(disc);
+    float root = (h - sq) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sq) / a;
+        if (!(tmin < root && root < tmax)) return -1.0f;
+    }
+    return root;
+}
+
+// aabb.h:48-62 for one box (the :41-46 guard is not reproduced)
+__device__ __forceinline__ bool slab(float bx0, float bx1, float by0, float by1, float bz0, float bz1, v3 o, v3 inv,
+                                     float lo, float hi) {
+    float t0 = (bx0 - o.x) * inv.x, t1 = (bx1 - o.x) * inv.x;
+    bool f = t0 < t1;
+    float nr = f ? t0 : t1, fr = f ? t1 : t0;
+    lo = nr > lo ? nr : lo; hi = fr < hi ? fr : hi;
+    t0 = (by0 - o.y) * inv.y; t1 = (by1 - o.y) * inv.y;
+    f = t0 < t1; nr = f ? t0 : t1; fr = f ? t1 : t0;
+    lo = nr > lo ? nr : lo; hi = fr < hi ? fr : hi;
+    t0 = (bz0 - o.z) * inv.z; t1 = (bz1 - o.z) * inv.z;
+    f = t0 < t1; nr = f ? t0 : t1; fr = f ? t1 : t0;
+    lo = nr > lo ? nr : lo; hi = fr < hi ? fr : hi;
+    // lo only grows and hi only shrinks, so "max <= min after some axis" == "at the end"
+    return !(hi <= lo);
+}
+
+struct hit_t { float t; int obj; };
+
+// hittable_list::hit, hittable_list.h:43-58
+template <bool IN_LDS, bool COUNT>
+__device__ __forceinline__ hit_t closest_hit_list(const float4* spheres, int n, const ray_t& r, uint32_t& n_tests) {
+    hit_t best; best.t = __builtin_huge_valf(); best.obj = -1;
+    const float a = len2(r.d);
+    for (int i = 0; i < n; ++i) {
+        const sphere_rec s = load_sphere<IN_LDS>(spheres, i);
+        const float root = sphere_root(s, r, a, 0.001f, best.t);
+        if (root > 0.0f) { best.t = root; best.obj = i; }
+    }
+    if (COUNT) n_tests += (uint32_t)n;
+    return best;
+}
+
+// external_hit, helper_experimental.h:1-50, over the implicit heap: left child first,
+// right child remembered in a bit mask, both children tested against the CURRENT
+// interval before descending.
+template <bool IN_LDS, bool COUNT>
+__device__ __forceinline__ hit_t closest_hit_bvh(const float4* pairs, const float4* spheres, int num_leaves,
+                                                 const ray_t& r, uint32_t& n_pairs, uint32_t& n_tests) {
+    hit_t best; best.t = __builtin_huge_valf(); best.obj = -1;
+    const float a = len2(r.d);
+    const float tmin = 0.001f;
+    if (num_leaves == 1) {  // the root is the only leaf: no box is tested (helper_experimental.h:16)
+        const sphere_rec s = load_sphere<IN_LDS>(spheres, __float_as_int(pairs[3].x));
+        const float root = sphere_root(s, r, a, tmin, best.t);
+        if (COUNT) n_tests += 1;
+        if (root > 0.0f) { best.t = root; best.obj = __float_as_int(pairs[3].x); }
+        return best;
+    }
+    const v3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);  // aabb.h:48
+    const uint32_t leaf_parents = (uint32_t)num_leaves >> 1;
+    uint32_t k = 1, pending = 0;
+    for (;;) {
+        const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+        const int tagL = __float_as_int(q3.x), tagR = __float_as_int(q3.y);
+        if (COUNT) n_pairs += 1;
+        const bool hitL = (tagL != CRT_TAG_EMPTY) && slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, r.o, inv, tmin, best.t);
+        const bool hitR = (tagR != CRT_TAG_EMPTY) && slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, r.o, inv, tmin, best.t);
+        bool pop;
+        if (k >= leaf_parents) {  // children are leaves: left sphere, then right sphere
+            if (hitL) {
+                const float root = sphere_root(load_sphere<IN_LDS>(spheres, tagL), r, a, tmin, best.t);
+                if (COUNT) n_tests += 1;
+                if (root > 0.0f) { best.t = root; best.obj = tagL; }
+            }
+            if (hitR) {
+                const float root = sphere_root(load_sphere<IN_LDS>(spheres, tagR), r, a, tmin, best.t);
+                if (COUNT) n_tests += 1;
+                if (root > 0.0f) { best.t = root; best.obj = tagR; }
+            }
+            pop = true;
+        } else if (hitL) {
+            pending = (pending << 1) | (hitR ? 1u : 0u);
+            k = 2 * k;
+            pop = false;
+        } else if (hitR) {
+            pending <<= 1;
+            k = 2 * k + 1;
+            pop = false;
+        } else {
+            pop = true;
+        }
+        if (pop) {
+            if (pending == 0) break;
+            const int up = __builtin_ctz(pending);
+            k = (k >> up) ^ 1u;  // the pending right sibling, `up` levels above
+            pending = (pending >> up) ^ 1u;
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ float reflectance(float cosine, float ri) {  // material.h:92-97, powf(x,5) as multiplies
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    const float x = 1.0f - cosine;
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    const float x5 = x4 * x;
+    return r0 + (1.0f - r0) * x5;
+}
+
+// One (pixel, sample) path state
+struct path_t {
+    ray_t r;
+    v3 thr;        // attenuation_mult
+    float sky_a;   // 0.5*(unit(primary dir).y + 1): the sky term uses the PRIMARY ray (D2)
+    int depth;
+};
+
+// hit record + material::scatter.  Returns false when the path ends; `rad` is the
+// radiance of the ended path (black on absorption).
+__device__ __forceinline__ bool shade(path_t& p, stream& rs, const sphere_rec& s, float4 mrec, float t) {
+    // sphere.h:66-70, hittable.h:16-22
+    const v3 pos = p.r.o + t * p.r.d;
+    const v3 cc = s.c + p.r.tm * s.mo;
+    const v3 outward = (1.0f / s.radius) * (pos - cc);
+    const bool front = dot(p.r.d, outward) < 0.0f;
+    const v3 nrm = front ? outward : -outward;
+    const int type = (uint32_t)s.mat >> CRT_MAT_TYPE_SHIFT;
+    if (type == 0) {  // lambertian, material.h:26-38
+        v3 dir = nrm + random_unit_vector(rs);
+        if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = nrm;
+        p.r.o = pos; p.r.d = dir;
+        p.thr = p.thr * mk(mrec.x, mrec.y, mrec.z);
+        return true;
+    } else if (type == 1) {  // metal, material.h:48-55
+        const v3 refl = p.r.d - (2.0f * dot(p.r.d, nrm)) * nrm;
+        const v3 dir = unit(refl) + (mrec.w * random_unit_vector(rs));
+        p.r.o = pos; p.r.d = dir;
+        p.thr = p.thr * mk(mrec.x, mrec.y, mrec.z);
+        return dot(dir, nrm) > 0.0f;
+    } else {  // dielectric, material.h:66-85
+        const float ri = front ? mrec.y : mrec.x;
+        const v3 ud = unit(p.r.d);
+        const float cos_theta = fminf(dot(-ud, nrm), 1.0f);
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool do_reflect = ri * sin_theta > 1.0f;
+        if (!do_reflect) do_reflect = reflectance(cos_theta, ri) > (1.0f - rs.next_block().x);
+        v3 dir;
+        if (do_reflect) {
+            dir = ud - (2.0f * dot(ud, nrm)) * nrm;
+        } else {  // refract, vec3.h:138-143
+            const v3 perp = ri * (ud + cos_theta * nrm);
+            const v3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * nrm;
+            dir = perp + par;
+        }
+        p.r.o = pos; p.r.d = dir;  // attenuation (1,1,1): thr * 1 == thr
+        return true;
+    }
+}
+
+__device__ __forceinline__ v3 sky(const path_t& p) {  // render_with_cuda.h:49-52
+    const float a = p.sky_a;
+    const v3 c = mk((1.0f - a) * 1.0f + a * 0.5f, (1.0f - a) * 1.0f + a * 0.7f, (1.0f - a) * 1.0f + a * 1.0f);
+    return p.thr * c;
+}
+
+__device__ __forceinline__ void start_path(path_t& p, stream& rs, const crt_render_args& a, int px, int py,
+                                           uint32_t pixel_index, uint32_t sample) {
+    rs.pixel = pixel_index; rs.sample = sample; rs.event = 0;
+    p.r = get_ray(rs, a.cam, px, py);
+    p.thr = mk(1.0f, 1.0f, 1.0f);
+    p.sky_a = 0.5f * (unit(p.r.d).y + 1.0f);
+    p.depth = 0;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) {
+    extern __shared__ float4 smem[];
+    constexpr int NW = BLOCK / 64;
+    const float4* pairs = (const float4*)a.pairs;
+    const float4* spheres = (const float4*)a.spheres;
+    const float4* mats = (const float4*)a.mats;
+    if (IN_LDS) {
+        const int np = (WORLD == 1) ? 4 * a.num_leaves : 0, ns = 2 * a.n, nm = a.m;
+        float4* s_pairs = smem;
+        float4* s_spheres = smem + np;
+        float4* s_mats = s_spheres + ns;
+        for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
+        for (int i = threadIdx.x; i < ns; i += BLOCK) s_spheres[i] = spheres[i];
+        for (int i = threadIdx.x; i < nm; i += BLOCK) s_mats[i] = mats[i];
+        __syncthreads();
+        pairs = s_pairs; spheres = s_spheres; mats = s_mats;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunks = a.chunks;  // power of two dividing NW
+    const int chunk = wave & (chunks - 1);
+    const int tile_local = wave / chunks;
+    const int tile = blockIdx.x * (NW / chunks) + tile_local;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    const bool valid = (ty < a.tiles_y) && (px < a.cam.width) && (py < a.cam.height);
+    const uint32_t pixel_index = (uint32_t)(py * a.cam.width + px);
+    const int c0 = chunk * a.chunk_spp;
+    const int c1 = min(a.ns, c0 + a.chunk_spp);
+
+    v3 acc = mk(0.0f, 0.0f, 0.0f);
+    uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
+    if (valid && c0 < c1) {
+        stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
+        path_t p;
+        int s = c0;
+        start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
+        for (;;) {
+            hit_t h;
+            if (WORLD == 1) h = closest_hit_bvh<IN_LDS, COUNT>(pairs, spheres, a.num_leaves, p.r, n_pairs, n_tests);
+            else h = closest_hit_list<IN_LDS, COUNT>(spheres, a.n, p.r, n_tests);
+            ++n_rays;
+            bool ended;
+            v3 rad = mk(0.0f, 0.0f, 0.0f);
+            if (h.obj >= 0) {
+                const sphere_rec sp = load_sphere<IN_LDS>(spheres, h.obj);
+                const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
+                const bool cont = shade(p, rs, sp, mrec, h.t);
+                ++p.depth;
+                ended = !cont || (p.depth >= a.max_depth);  // absorbed or loop exhausted: black
+            } else {
+                rad = sky(p);
+                ended = true;
+            }
+            if (ended) {
+                acc = acc + rad;
+                ++n_samples;
+                ++s;
+                if (s >= c1) break;
+                start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
+            }
+        }
+    }
+
+    // statistics: one atomic per wave and counter
+    {
+        const uint32_t r = wave_sum(n_rays), sm = wave_sum(n_samples);
+        if (lane == 0 && r) { atomicAdd(&a.counters[0], (unsigned long long)r); atomicAdd(&a.counters[1], (unsigned long long)sm); }
+        if (COUNT) {
+            const uint32_t pv = wave_sum(n_pairs), st = wave_sum(n_tests);
+            if (lane == 0) { atomicAdd(&a.counters[2], (unsigned long long)pv); atomicAdd(&a.counters[3], (unsigned long long)st); }
+        }
+    }
+
+    // chunk sums -> framebuffer, in chunk order (LDS is reused: every wave is past its traversal)
+    float* red = (float*)smem;
+    if (chunks > 1) {
+        __syncthreads();
+        red[(wave * 3 + 0) * 64 + lane] = acc.x;
+        red[(wave * 3 + 1) * 64 + lane] = acc.y;
+        red[(wave * 3 + 2) * 64 + lane] = acc.z;
+        __syncthreads();
+    }
+    if (chunk == 0 && valid) {
+        float* out = a.sums + 3 * (size_t)pixel_index;
+        float r = out[0], g = out[1], b = out[2];
+        if (chunks > 1) {
+            const int used = (a.ns + a.chunk_spp - 1) / a.chunk_spp;  // non-empty chunks
+            for (int c = 0; c < used; ++c) {
+                const int w = tile_local * chunks + c;
+                r += red[(w * 3 + 0) * 64 + lane];
+                g += red[(w * 3 + 1) * 64 + lane];
+                b += red[(w * 3 + 2) * 64 + lane];
+            }
+        } else {
+            r += acc.x; g += acc.y; b += acc.z;
+        }
+        out[0] = r; out[1] = g; out[2] = b;
+    }
+}
+
+// single paths, for fine-grained parity checks (same device functions as the render kernel)
+template <int WORLD>
+__global__ __launch_bounds__(64) void trace_samples_kernel(const crt_render_args a, int count, const int* pxs,
+                                                           const int* pys, const int* samples, float* ray7,
+                                                           float* rgb, int* segments) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const float4* pairs = (const float4*)a.pairs;
+    const float4* spheres = (const float4*)a.spheres;
+    const float4* mats = (const float4*)a.mats;
+    const int px = pxs[i], py = pys[i];
+    stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
+    path_t p;
+    start_path(p, rs, a, px, py, (uint32_t)(py * a.cam.width + px), (uint32_t)samples[i]);
+    ray7[7 * i + 0] = p.r.o.x; ray7[7 * i + 1] = p.r.o.y; ray7[7 * i + 2] = p.r.o.z;
+    ray7[7 * i + 3] = p.r.d.x; ray7[7 * i + 4] = p.r.d.y; ray7[7 * i + 5] = p.r.d.z;
+    ray7[7 * i + 6] = p.r.tm;
+    v3 rad = mk(0.0f, 0.0f, 0.0f);
+    int segs = 0;
+    uint32_t d0 = 0, d1 = 0;
+    for (;;) {
+        hit_t h;
+        if (WORLD == 1) h = closest_hit_bvh<false, false>(pairs, spheres, a.num_leaves, p.r, d0, d1);
+        else h = closest_hit_list<false, false>(spheres, a.n, p.r, d1);
+        ++segs;
+        if (h.obj >= 0) {
+            const sphere_rec sp = load_sphere<false>(spheres, h.obj);
+            const bool cont = shade(p, rs, sp, mats[sp.mat & CRT_MAT_ID_MASK], h.t);
+            ++p.depth;
+            if (!cont || p.depth >= a.max_depth) break;
+        } else {
+            rad = sky(p);
+            break;
+        }
+    }
+    rgb[3 * i + 0] = rad.x; rgb[3 * i + 1] = rad.y; rgb[3 * i + 2] = rad.z;
+    segments[i] = segs;
+}
+
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
+hipError_t launch_one(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
+    auto k = render_kernel<WORLD, IN_LDS, COUNT, BLOCK>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+template <int WORLD, bool IN_LDS, bool COUNT>
+hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t lds_bytes, hipStream_t stream) {
+    switch (block) {
+        case 256: return launch_one<WORLD, IN_LDS, COUNT, 256>(a, grid, lds_bytes, stream);
+        case 512: return launch_one<WORLD, IN_LDS, COUNT, 512>(a, grid, lds_bytes, stream);
+        case 1024: return launch_one<WORLD, IN_LDS, COUNT, 1024>(a, grid, lds_bytes, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// Host-visible launchers (called from crt_api.cpp)
+hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
+                             size_t lds_bytes, hipStream_t stream) {
+    if (world == 1) {
+        if (in_lds) return count ? launch_block<1, true, true>(a, block, grid, lds_bytes, stream)
+                                 : launch_block<1, true, false>(a, block, grid, lds_bytes, stream);
+        return count ? launch_block<1, false, true>(a, block, grid, lds_bytes, stream)
+                     : launch_block<1, false, false>(a, block, grid, lds_bytes, stream);
+    }
+    if (in_lds) return count ? launch_block<0, true, true>(a, block, grid, lds_bytes, stream)
+                             : launch_block<0, true, false>(a, block, grid, lds_bytes, stream);
+    return count ? launch_block<0, false, true>(a, block, grid, lds_bytes, stream)
+                 : launch_block<0, false, false>(a, block, grid, lds_bytes, stream);
+}
+
+hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
+                                    const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream) {
+    const int grid = (count + 63) / 64;
+    if (world == 1) hipLaunchKernelGGL(trace_samples_kernel<1>, dim3(grid), dim3(64), 0, stream, a, count, px, py, samples, ray7, rgb, segments);
+    else hipLaunchKernelGGL(trace_samples_kernel<0>, dim3(grid), dim3(64), 0, stream, a, count, px, py, samples, ray7, rgb, segments);
+    return hipGetLastError();
+}

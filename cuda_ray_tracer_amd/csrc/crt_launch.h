@@ -1,0 +1,14 @@
+// crt_launch.h -- launchers defined in crt_kernels.hip, called from crt_api.cpp
+#ifndef CRT_LAUNCH_H
+#define CRT_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "crt_device.h"
+
+hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
+                             size_t lds_bytes, hipStream_t stream);
+hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
+                                    const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream);
+
+#endif

@@ -1,0 +1,188 @@
+/* crt_hip.h -- C ABI of libcrt_hip.so, the MI355X (gfx950) implementation of the one hot path
+ * of ChenVand/CUDA_Ray_Tracer: the per-sample Monte Carlo loop of render_with_cuda.h
+ * (get_ray -> closest hit over spheres / flat BVH -> lambertian|metal|dielectric scatter
+ * chain -> per-pixel accumulation).
+ *
+ * The reference has no FFI; its boundary is the host C++ call `render()` /
+ * `render_experimental()` plus the scene classes the CLI constructs.  The
+ * host classes in cuda_ray_tracer_amd/host/ keep those names and flatten onto the entry
+ * points below.  Every entry point cites the reference interface it replaces
+ * (file:line relative to the reference root).  Plain pointers and sizes only.
+ *
+ * Conventions: every function returns 0 (CRT_OK) or a CRT_ERR_* code and never calls
+ * exit(); crt_last_error() gives the message.  A context is not re-entrant; separate
+ * contexts are independent.  All float data is fp32.  Framebuffers are W*H*3 floats,
+ * row-major, RGB interleaved -- the layout of the reference's `vec3 fb[W*H]`
+ * (helper.h:139-141).
+ */
+#ifndef CRT_HIP_H
+#define CRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_OK 0
+#define CRT_ERR_INVALID_ARGUMENT 1
+#define CRT_ERR_NO_DEVICE 2
+#define CRT_ERR_HIP 3
+#define CRT_ERR_STATE 4
+#define CRT_ERR_TOO_LARGE 5
+
+/* material.h:22-98 -- the three subclasses, flattened to a tag */
+#define CRT_LAMBERTIAN 0
+#define CRT_METAL 1
+#define CRT_DIELECTRIC 2
+
+/* which `world` the bounce loop queries */
+#define CRT_WORLD_LIST 0 /* hittable_list::hit, hittable_list.h:43-58  (render(),              helper.h:111)             */
+#define CRT_WORLD_BVH 1  /* external_hit,       helper_experimental.h:1-50 (render_experimental(), helper_experimental.h:148) */
+
+typedef struct crt_context crt_context;
+
+/* camera.h:11-22 -- the public configuration fields */
+typedef struct crt_camera_params {
+    float aspect_ratio;
+    int32_t image_width;
+    int32_t samples_per_pixel;
+    float vfov;
+    float lookfrom[3];
+    float lookat[3];
+    float vup[3];
+    float defocus_angle;
+    float focus_dist;
+} crt_camera_params;
+
+/* camera.h:60-68 -- what initialize() derives and the kernel reads through the getters
+ * (camera.h:26-40) */
+typedef struct crt_camera {
+    int32_t image_width;
+    int32_t image_height;
+    float pixel_samples_scale;
+    float center[3];
+    float pixel00_loc[3];
+    float pixel_delta_u[3];
+    float pixel_delta_v[3];
+    float defocus_disk_u[3];
+    float defocus_disk_v[3];
+    float defocus_angle;
+} crt_camera;
+
+/* bvh.h:47-62 -- bvh_node, same field order and size (36 B).  Fields the reference
+ * leaves uninitialised (children of leaves; loc/children of padding leaves) read -1. */
+typedef struct crt_bvh_node {
+    float xmin, xmax, ymin, ymax, zmin, zmax; /* aabb: interval x, y, z */
+    int32_t loc_for_leaf;
+    int32_t left_child_loc;
+    int32_t right_child_loc;
+} crt_bvh_node;
+
+typedef struct crt_render_stats {
+    double kernel_seconds;  /* device time of the render kernel(s) of the last call (HIP events on its stream) */
+    double wall_seconds;    /* host wall time of the last crt_render call (helper.h:144-170 timer_seconds) */
+    uint64_t rays;          /* closest-hit queries = world.hit calls, render_with_cuda.h:41 */
+    uint64_t samples;       /* (pixel, sample) paths traced */
+    uint64_t pair_visits;   /* BVH internal nodes visited (two child boxes tested each); counted only with crt_set_count_stats(1) */
+    uint64_t sphere_tests;  /* sphere::hit evaluations; counted only with crt_set_count_stats(1) */
+} crt_render_stats;
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------ */
+
+/* camera::initialize(), camera.h:72-107 */
+int crt_camera_initialize(const crt_camera_params* params, crt_camera* out);
+
+/* create_world, helper.h:7-35 (same five spheres as create_objects, main_experimental.cu:38-54).
+ * Arrays need room for 5 spheres / 5 materials.  *n_out <- 5. */
+int crt_scene_small(float* center, float* motion, float* radius, int32_t* mat_id, int32_t* mat_type,
+                    float* mat_albedo, float* mat_param, int32_t* n_out);
+
+/* create_world2, helper.h:37-102, generalised: (2*half)^2 grid cells (half = 11 in the
+ * reference), ground sphere of `ground_radius` (1000 in the reference).  One material per
+ * sphere.  `capacity` >= 4 + 4*half*half.  The reference seeds cuRAND with 18
+ * (helper.h:41); `seed` keys the Philox scene stream. */
+int crt_scene_random(uint64_t seed, int32_t half, float ground_radius, int32_t capacity, float* center,
+                     float* motion, float* radius, int32_t* mat_id, int32_t* mat_type, float* mat_albedo,
+                     float* mat_param, int32_t* n_out);
+
+/* camera::display_frame + write_color, camera.h:44-57, color.h:9-35: P3 text PPM of a
+ * normalised framebuffer.  Returns bytes needed; writes at most `cap` bytes when buf != NULL. */
+int64_t crt_write_ppm(const float* fb, int32_t width, int32_t height, char* buf, int64_t cap);
+
+/* bvh_world ctor on plain host arrays (bvh.h:135-192, :251-274, :64-100): the node array
+ * for n spheres, without a context or a GPU.  nodes needs crt_bvh_num_nodes(n) entries. */
+int32_t crt_bvh_num_nodes(int32_t n);
+int crt_bvh_build_host(int32_t n, const float* center, const float* motion, const float* radius,
+                       uint32_t axis_seed, crt_bvh_node* nodes);
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Replaces the implicit CUDA context + time(0) seeding (helper.h:134).  `seed` keys every
+ * per-(pixel, sample) Philox stream. */
+int crt_create(int32_t device, uint64_t seed, crt_context** out);
+int crt_destroy(crt_context* ctx);
+/* message of the last failure on ctx (or of the last failed crt_create when ctx == NULL) */
+const char* crt_last_error(const crt_context* ctx);
+int crt_set_seed(crt_context* ctx, uint64_t seed);
+
+/* Replaces create_world<<<1,1>>> / create_objects<<<1,1>>> + the device-side `new`s
+ * (helper.h:7-102, main_experimental.cu:38-54, :121-132): n spheres as flat arrays
+ * (center[3n], motion[3n] = center2 - center1 or 0, radius[n], mat_id[n]) and m materials
+ * (type[m], albedo[3m], param[m] = fuzz | refraction_index).  The library copies; the
+ * caller keeps ownership.  Drops any BVH built before. */
+int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const float* motion, const float* radius,
+                     const int32_t* mat_id, int32_t m, const int32_t* mat_type, const float* mat_albedo,
+                     const float* mat_param);
+
+/* bvh_world::bvh_world(object_list, n), bvh.h:135-192.  axis_seed is 17 in the reference
+ * (bvh.h:144).  *num_nodes_out <- 2^(depth+1)-1. */
+int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out);
+/* read-back of bvh_world::d_nodes (bvh.h:131) for the bit-exact check */
+int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity);
+
+/* the managed `camera*` the kernels dereference (main_experimental.cu:99-116) */
+int crt_set_camera(crt_context* ctx, const crt_camera* cam);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+
+/* render(), helper.h:111-171 (world = CRT_WORLD_LIST) and render_experimental(),
+ * helper_experimental.h:148-213 (world = CRT_WORLD_BVH): traces samples
+ * [sample_offset, sample_offset + cam.samples_per_pixel ... see `spp`) of every pixel and
+ * writes the normalised framebuffer (sum * 1/spp) to the caller's host buffer.
+ * max_depth is the bounce limit (50 in render_with_cuda.h:33). */
+int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
+               float* fb_host, crt_render_stats* stats);
+
+/* The same launch without the host round trip: ADDS the un-normalised per-pixel sums of
+ * samples [sample_offset, sample_offset + nsamples) to the device buffer d_sums (W*H*3
+ * floats) on `stream` (a hipStream_t; NULL = default stream).  Asynchronous.  This is
+ * what multi-GPU sample splitting and progressive accumulation call. */
+int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
+                          int32_t max_depth, float* d_sums, void* stream);
+
+/* Waits for the last launch and returns its statistics. */
+int crt_get_stats(crt_context* ctx, crt_render_stats* stats);
+
+/* Summation contract: per pixel the samples of one call are summed in fp32 sequentially
+ * in sample order inside chunks of crt_chunk_spp() consecutive samples, and the chunk
+ * sums are added to the buffer in chunk order.  Returns that chunk size for a call of
+ * `nsamples` samples (it depends on nsamples and on crt_set_chunks only). */
+int32_t crt_chunk_spp(const crt_context* ctx, int32_t nsamples);
+/* 0 = automatic; otherwise the number of sample chunks a workgroup splits a pixel tile
+ * into (1, 2, 4, 8 or 16). */
+int crt_set_chunks(crt_context* ctx, int32_t chunks);
+/* enable (1) / disable (0) the pair_visits / sphere_tests counters (slower kernel variant) */
+int crt_set_count_stats(crt_context* ctx, int32_t enable);
+
+/* Debug/parity: primary ray (7 floats), radiance (3 floats) and number of closest-hit
+ * queries of single (pixel, sample) paths, computed by the same device functions as the
+ * render kernel.  px/py/sample are arrays of `count` entries; outputs are host buffers. */
+int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int32_t* px, const int32_t* py,
+                      const int32_t* sample, int32_t max_depth, float* ray7_out, float* rgb_out,
+                      int32_t* segments_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_HIP_H */

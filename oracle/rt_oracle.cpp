@@ -1,0 +1,796 @@
+// rt_oracle.cpp -- CPU ORACLE. TEST INFRASTRUCTURE ONLY.
+//
+// A scalar C++ restatement of the hot path of ChenVand/CUDA_Ray_Tracer (the per-sample
+// Monte Carlo loop of render_with_cuda.h and everything it calls).  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+// product (cuda_ray_tracer_amd/) never does.
+//
+// PARITY STATUS: "parity unpinned" by the reference itself -- the reference holds no
+// tests, golden vectors or fixtures for this path and cannot be built
+// here (it needs nvcc, cuRAND and Thrust-CUDA; writing stand-ins for those is not
+// allowed).  What IS pinned, against real third-party code present in this image:
+//   * Philox4x32-10 + the (0,1] float mapping  -> rocRAND's own header (oracle/pin/)
+//     and the Random123 known-answer vectors;
+//   * the BVH split-axis sequence               -> rocThrust's minstd_rand +
+//     uniform_int_distribution (oracle/pin/), which is what bvh.h:144-147,257 calls;
+//   * camera::initialize                        -> closed-form values in tests.
+// Everything else is a line-by-line restatement; each function cites the lines it follows
+// (paths relative to the reference root).
+//
+// Build: g++ -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  No -ffast-math,
+// no contraction: every fp32 operation is one IEEE-754 rounding, which is the contract
+// the HIP kernels are held to.
+//
+// Decisions on reference defects are marked "D<n>".
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// rtweekend.h:11-18
+const float infinity = std::numeric_limits<float>::infinity();
+const float pi = 3.1415926535897932385;
+
+inline float degrees_to_radians(float degrees) {
+    return degrees * pi / 180.0;  // float*float, then double divide, rounded to float
+}
+
+// ---------------------------------------------------------------------------------------
+// RNG.  The reference uses cuRAND XORWOW seeded with time(0) (render_with_cuda.h:113,
+// helper.h:134), so no reference output is reproducible (D11).  Replacement:
+// Philox4x32-10, key = 64-bit seed, counter = (event, sample, pixel, stream tag).
+// This equals rocRAND's rocrand_init(seed, subsequence = pixel | tag<<32,
+// offset = (sample<<34) + 4*event).
+struct u32x4 { uint32_t x, y, z, w; };
+
+inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t m0 = (uint64_t)0xD2511F53u * c.x;
+        uint64_t m1 = (uint64_t)0xCD9E8D57u * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(m1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)m1;
+        n.z = (uint32_t)(m0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)m0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// curand_uniform stand-in: (0,1], rocRAND's mapping (rocrand_uniform.h:65-68).
+inline float u01(uint32_t v) { return 2.3283064e-10f + (v * 2.3283064e-10f); }
+
+struct f4 { float x, y, z, w; };
+
+// One (pixel, sample) stream of the render: hands out whole Philox blocks ("events").
+// Draw plan (DESIGN.md "RNG draw plan"): the reference's draws are grouped so that each
+// rejection-loop attempt / decision consumes one block; unused lanes are discarded.
+struct sample_stream {
+    uint32_t k0, k1, pixel, sample, event;
+    sample_stream(uint64_t seed, uint32_t pixel_, uint32_t sample_)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), pixel(pixel_), sample(sample_), event(0) {}
+    f4 next_block() {
+        u32x4 r = philox4x32_10(u32x4{event, sample, pixel, 0u}, k0, k1);
+        ++event;
+        return f4{u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+    }
+};
+
+// Sequential one-draw-at-a-time stream (scene generation; stream tag 1).  Equals
+// rocrand_uniform() on rocrand_init(seed, 1ull<<32, 0).
+struct seq_stream {
+    uint32_t k0, k1, block, lane;
+    u32x4 buf;
+    explicit seq_stream(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), block(0), lane(4) {}
+    float curand_uniform() {
+        if (lane == 4) { buf = philox4x32_10(u32x4{block++, 0u, 0u, 1u}, k0, k1); lane = 0; }
+        uint32_t v = lane == 0 ? buf.x : lane == 1 ? buf.y : lane == 2 ? buf.z : buf.w;
+        ++lane;
+        return u01(v);
+    }
+    // rtweekend.h:20-28
+    float random_float() { return 1 - curand_uniform(); }
+    float random_float(float min, float max) { return min + (max - min) * (1 - curand_uniform()); }
+};
+
+// ---------------------------------------------------------------------------------------
+// vec3.h:5-143
+struct vec3 {
+    float e[3];
+    vec3() : e{0, 0, 0} {}
+    vec3(float e0, float e1, float e2) : e{e0, e1, e2} {}
+    float x() const { return e[0]; }
+    float y() const { return e[1]; }
+    float z() const { return e[2]; }
+    vec3 operator-() const { return vec3(-e[0], -e[1], -e[2]); }
+    float operator[](int i) const { return e[i]; }
+    vec3& operator+=(const vec3& v) { e[0] += v.e[0]; e[1] += v.e[1]; e[2] += v.e[2]; return *this; }
+    vec3& operator*=(const vec3& v) { e[0] *= v.e[0]; e[1] *= v.e[1]; e[2] *= v.e[2]; return *this; }
+    float length_squared() const { return e[0] * e[0] + e[1] * e[1] + e[2] * e[2]; }
+    float length() const { return sqrtf(length_squared()); }
+    bool near_zero() const {  // vec3.h:62-66 -- the threshold is a double
+        auto s = 1e-8;
+        return (fabsf(e[0]) < s) && (fabsf(e[1]) < s) && (fabsf(e[2]) < s);
+    }
+};
+using point3 = vec3;
+using color = vec3;
+
+inline vec3 operator+(const vec3& u, const vec3& v) { return vec3(u.e[0] + v.e[0], u.e[1] + v.e[1], u.e[2] + v.e[2]); }
+inline vec3 operator-(const vec3& u, const vec3& v) { return vec3(u.e[0] - v.e[0], u.e[1] - v.e[1], u.e[2] - v.e[2]); }
+inline vec3 operator*(const vec3& u, const vec3& v) { return vec3(u.e[0] * v.e[0], u.e[1] * v.e[1], u.e[2] * v.e[2]); }
+inline vec3 operator*(float t, const vec3& v) { return vec3(t * v.e[0], t * v.e[1], t * v.e[2]); }
+inline vec3 operator*(const vec3& v, float t) { return t * v; }
+inline vec3 operator/(const vec3& v, float t) { return (1 / t) * v; }  // vec3.h:114-116
+inline float dot(const vec3& u, const vec3& v) { return u.e[0] * v.e[0] + u.e[1] * v.e[1] + u.e[2] * v.e[2]; }
+inline vec3 cross(const vec3& u, const vec3& v) {
+    return vec3(u.e[1] * v.e[2] - u.e[2] * v.e[1], u.e[2] * v.e[0] - u.e[0] * v.e[2], u.e[0] * v.e[1] - u.e[1] * v.e[0]);
+}
+inline vec3 unit_vector(const vec3& v) { return v / v.length(); }
+inline vec3 reflect(const vec3& v, const vec3& n) { return v - 2 * dot(v, n) * n; }
+inline vec3 refract(const vec3& uv, const vec3& n, float etai_over_etat) {  // vec3.h:138-143
+    auto cos_theta = fminf(dot(-uv, n), 1.0);
+    vec3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    vec3 r_out_parallel = -sqrtf(fabsf(1.0 - r_out_perp.length_squared())) * n;
+    return r_out_perp + r_out_parallel;
+}
+
+// vec3.h:145-152.  One block per attempt: x,y,z <- lanes 0..2.  "1e-80 < lensq" is a
+// double compare, true for every positive float (D15).
+inline vec3 random_unit_vector(sample_stream& rs) {
+    while (true) {
+        f4 b = rs.next_block();
+        auto p = vec3(-1 + (1 - -1) * (1 - b.x), -1 + (1 - -1) * (1 - b.y), -1 + (1 - -1) * (1 - b.z));
+        auto lensq = p.length_squared();
+        if (1e-80 < lensq && lensq <= 1) return p / sqrtf(lensq);
+    }
+}
+
+// vec3.h:154-160.  One block carries two attempts: (x,y) then (z,w).
+inline vec3 random_in_unit_disk(sample_stream& rs) {
+    while (true) {
+        f4 b = rs.next_block();
+        auto p = vec3(-1 + (1 - -1) * (1 - b.x), -1 + (1 - -1) * (1 - b.y), 0);
+        if (p.length_squared() < 1) return p;
+        p = vec3(-1 + (1 - -1) * (1 - b.z), -1 + (1 - -1) * (1 - b.w), 0);
+        if (p.length_squared() < 1) return p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// interval.h:4-49
+struct interval {
+    float min, max;
+    interval() : min(+infinity), max(-infinity) {}
+    interval(float mn, float mx) : min(mn), max(mx) {}
+    interval(const interval& a, const interval& b) {
+        min = a.min <= b.min ? a.min : b.min;
+        max = a.max >= b.max ? a.max : b.max;
+    }
+    bool contains(float x) const { return min <= x && x <= max; }
+    bool surrounds(float x) const { return min < x && x < max; }
+    float clamp(float x) const { if (x < min) return min; if (x > max) return max; return x; }
+};
+
+// ray.h:6-29
+struct ray {
+    point3 orig; vec3 dir; float tm;
+    ray() : tm(0) {}
+    ray(const point3& o, const vec3& d, float t) : orig(o), dir(d), tm(t) {}
+    const point3& origin() const { return orig; }
+    const vec3& direction() const { return dir; }
+    float time() const { return tm; }
+    point3 at(float t) const { return orig + t * dir; }
+};
+
+// aabb.h:4-32, 69-71
+struct aabb {
+    interval x, y, z;
+    aabb() {}
+    aabb(const interval& x_, const interval& y_, const interval& z_) : x(x_), y(y_), z(z_) {}
+    aabb(const point3& a, const point3& b) {
+        x = (a[0] <= b[0]) ? interval(a[0], b[0]) : interval(b[0], a[0]);
+        y = (a[1] <= b[1]) ? interval(a[1], b[1]) : interval(b[1], a[1]);
+        z = (a[2] <= b[2]) ? interval(a[2], b[2]) : interval(b[2], a[2]);
+    }
+    aabb(const aabb& b0, const aabb& b1) : x(b0.x, b1.x), y(b0.y, b1.y), z(b0.z, b1.z) {}
+    const interval& axis_interval(int n) const { if (n == 1) return y; if (n == 2) return z; return x; }
+    bool is_empty() const { return x.min > x.max; }
+
+    // aabb.h:34-65 with lines 41-46 removed (D1: the as-written guard makes every ray
+    // with a direction component >= 1e-10 miss).  This is the RTOW slab test the code
+    // evidently meant.  An empty box never hits (D5).
+    bool hit(const ray& r, interval ray_t) const {
+        if (is_empty()) return false;
+        const point3& ray_orig = r.origin();
+        const vec3& ray_dir = r.direction();
+        for (int axis = 0; axis < 3; axis++) {
+            const interval& ax = axis_interval(axis);
+            const float adinv = 1.0 / ray_dir[axis];
+            auto t0 = (ax.min - ray_orig[axis]) * adinv;
+            auto t1 = (ax.max - ray_orig[axis]) * adinv;
+            if (t0 < t1) {
+                if (t0 > ray_t.min) ray_t.min = t0;
+                if (t1 < ray_t.max) ray_t.max = t1;
+            } else {
+                if (t1 > ray_t.min) ray_t.min = t1;
+                if (t0 < ray_t.max) ray_t.max = t0;
+            }
+            if (ray_t.max <= ray_t.min) return false;
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// material.h (flattened: type 0 lambertian :22-42, 1 metal :44-60, 2 dielectric :62-98)
+struct material {
+    int type;
+    color albedo;
+    float param;  // metal: fuzz (already clamped, material.h:46); dielectric: refraction_index
+};
+
+// hittable.h:8-23
+struct hit_record {
+    point3 p; vec3 normal; int mat; float t; bool front_face;
+    void set_face_normal(const ray& r, const vec3& outward_normal) {
+        front_face = dot(r.direction(), outward_normal) < 0;
+        normal = front_face ? outward_normal : -outward_normal;
+    }
+};
+
+// sphere.h:6-73
+struct sphere {
+    ray center; float radius; int mat; aabb bbox;
+    sphere() : radius(0), mat(0) {}
+    sphere(const point3& c1, const vec3& motion, float r, int m, bool moving)
+        : center(c1, motion, 0), radius(fmaxf(0, r)), mat(m) {
+        auto rvec = vec3(r, r, r);
+        if (!moving) {
+            bbox = aabb(c1 - rvec, c1 + rvec);  // sphere.h:12-13
+        } else {
+            aabb box1(center.at(0) - rvec, center.at(0) + rvec);  // sphere.h:21-24
+            aabb box2(center.at(1) - rvec, center.at(1) + rvec);
+            bbox = aabb(box1, box2);
+        }
+    }
+    bool hit(const ray& r, interval ray_t, hit_record& rec) const {  // sphere.h:44-73
+        point3 current_center = center.at(r.time());
+        vec3 oc = current_center - r.origin();
+        auto a = r.direction().length_squared();
+        auto h = dot(r.direction(), oc);
+        auto c = oc.length_squared() - radius * radius;
+        auto discriminant = h * h - a * c;
+        if (discriminant < 0) return false;
+        auto sqrtd = sqrtf(discriminant);
+        auto root = (h - sqrtd) / a;
+        if (!ray_t.surrounds(root)) {
+            root = (h + sqrtd) / a;
+            if (!ray_t.surrounds(root)) return false;
+        }
+        rec.t = root;
+        rec.p = r.at(rec.t);
+        vec3 outward_normal = (rec.p - current_center) / radius;
+        rec.set_face_normal(r, outward_normal);
+        rec.mat = mat;
+        return true;
+    }
+};
+
+// bvh.h:47-62.  36 bytes, same field order as the reference.  Fields the reference leaves
+// uninitialised (children of leaves, everything but bbox of padding leaves) are -1 here.
+struct bvh_node {
+    float xmin, xmax, ymin, ymax, zmin, zmax;
+    int loc_for_leaf, left_child_loc, right_child_loc;
+};
+static_assert(sizeof(bvh_node) == 36, "bvh_node layout");
+
+inline aabb node_box(const bvh_node& n) {
+    return aabb(interval(n.xmin, n.xmax), interval(n.ymin, n.ymax), interval(n.zmin, n.zmax));
+}
+
+struct counters { uint64_t rays = 0, pair_visits = 0, sphere_tests = 0, samples = 0; };
+
+struct scene {
+    std::vector<sphere> objects;
+    std::vector<material> materials;
+    const bvh_node* nodes = nullptr;  // null -> brute-force hittable_list
+    int num_nodes = 0;
+};
+
+// hittable_list.h:43-58
+bool list_hit(const scene& w, const ray& r, interval ray_t, hit_record& rec, counters& ct) {
+    hit_record temp_rec;
+    bool hit_anything = false;
+    auto closest_so_far = ray_t.max;
+    for (size_t i = 0; i < w.objects.size(); ++i) {
+        ct.sphere_tests++;
+        if (w.objects[i].hit(r, interval(ray_t.min, closest_so_far), temp_rec)) {
+            hit_anything = true;
+            closest_so_far = temp_rec.t;
+            rec = temp_rec;
+        }
+    }
+    return hit_anything;
+}
+
+// helper_experimental.h:1-50.  As written the leaf branch never pops (the do/while would
+// spin on the leaf for ever); the evident intent -- pop after a leaf -- is restated.
+// Padding leaves / all-padding subtrees carry an empty box and are never entered (D5).
+bool external_hit(const scene& w, const ray& r, interval ray_t, hit_record& rec, counters& ct) {
+    hit_record temp_rec;
+    bool hit_anything = false;
+    auto current_interval = ray_t;
+    int stack[64];
+    int* stackPtr = stack;
+    *stackPtr++ = -1;  // push sentinel
+    int node = 0;      // root, assumed hit
+    if (w.num_nodes == 0) return false;
+    do {
+        const bvh_node& nd = w.nodes[node];
+        if (nd.loc_for_leaf > -1) {
+            ct.sphere_tests++;
+            if (w.objects[nd.loc_for_leaf].hit(r, current_interval, temp_rec)) {
+                hit_anything = true;
+                current_interval.max = temp_rec.t;
+                rec = temp_rec;
+            }
+            node = *--stackPtr;
+        } else if (nd.left_child_loc < 0) {
+            node = *--stackPtr;  // padding leaf reached only if it is the root's whole tree
+        } else {
+            ct.pair_visits++;
+            int childL = nd.left_child_loc, childR = nd.right_child_loc;
+            bool left_hit = node_box(w.nodes[childL]).hit(r, current_interval);
+            bool right_hit = node_box(w.nodes[childR]).hit(r, current_interval);
+            if (left_hit) {
+                node = childL;
+                if (right_hit) *stackPtr++ = childR;
+            } else if (right_hit) {
+                node = childR;
+            } else {
+                node = *--stackPtr;
+            }
+        }
+    } while (node != -1);
+    return hit_anything;
+}
+
+// material.h:92-97.  powf(x,5) is restated as exact multiplies so that device and host
+// libm cannot disagree: x2=x*x, x4=x2*x2, x5=x4*x (within 2 ulp of powf).
+inline float reflectance(float cosine, float refraction_index) {
+    auto r0 = (1 - refraction_index) / (1 + refraction_index);
+    r0 = r0 * r0;
+    float x = (1 - cosine);
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    float x5 = x4 * x;
+    return r0 + (1 - r0) * x5;
+}
+
+bool scatter(const material& m, sample_stream& rs, const ray& r_in, const hit_record& rec,
+             color& attenuation, ray& scattered) {
+    if (m.type == 0) {  // material.h:26-38
+        auto scatter_direction = rec.normal + random_unit_vector(rs);
+        if (scatter_direction.near_zero()) scatter_direction = rec.normal;
+        scattered = ray(rec.p, scatter_direction, r_in.time());
+        attenuation = m.albedo;
+        return true;
+    } else if (m.type == 1) {  // material.h:48-55
+        vec3 reflected = reflect(r_in.direction(), rec.normal);
+        reflected = unit_vector(reflected) + (m.param * random_unit_vector(rs));
+        scattered = ray(rec.p, reflected, r_in.time());
+        attenuation = m.albedo;
+        return (dot(scattered.direction(), rec.normal) > 0);
+    } else {  // material.h:66-85
+        attenuation = color(1.0, 1.0, 1.0);
+        float ri = rec.front_face ? (1.0 / m.param) : m.param;
+        vec3 unit_direction = unit_vector(r_in.direction());
+        float cos_theta = fminf(dot(-unit_direction, rec.normal), 1.0);
+        float sin_theta = sqrtf(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0;
+        vec3 direction;
+        // the draw is short-circuited away under total internal reflection (material.h:78)
+        if (cannot_refract || reflectance(cos_theta, ri) > (1 - rs.next_block().x))
+            direction = reflect(unit_direction, rec.normal);
+        else
+            direction = refract(unit_direction, rec.normal, ri);
+        scattered = ray(rec.p, direction, r_in.time());
+        return true;
+    }
+}
+
+// camera.h:9-107 (host).  "derived" is what the kernel reads through the getters.
+struct camera_params {
+    float aspect_ratio; int image_width; int samples_per_pixel; float vfov;
+    float lookfrom[3], lookat[3], vup[3];
+    float defocus_angle, focus_dist;
+};
+struct camera_derived {
+    int image_width, image_height; float pixel_samples_scale;
+    float center[3], pixel00_loc[3], pixel_delta_u[3], pixel_delta_v[3], defocus_disk_u[3], defocus_disk_v[3];
+    float defocus_angle;
+};
+inline void put(float* d, const vec3& v) { d[0] = v.x(); d[1] = v.y(); d[2] = v.z(); }
+inline vec3 get(const float* d) { return vec3(d[0], d[1], d[2]); }
+
+void camera_initialize(const camera_params& c, camera_derived& o) {  // camera.h:72-107
+    int image_width = c.image_width;
+    int image_height = int(image_width / c.aspect_ratio);
+    image_height = (image_height < 1) ? 1 : image_height;
+    float pixel_samples_scale = 1.0 / c.samples_per_pixel;
+    point3 lookfrom = get(c.lookfrom), lookat = get(c.lookat);
+    vec3 vup = get(c.vup);
+    float focus_dist = c.focus_dist;
+    point3 center = lookfrom;
+    auto theta = degrees_to_radians(c.vfov);
+    auto h = std::tan(theta / 2);
+    auto viewport_height = 2 * h * focus_dist;
+    auto viewport_width = viewport_height * (double(image_width) / image_height);  // double
+    vec3 w = unit_vector(lookfrom - lookat);
+    vec3 u = unit_vector(cross(vup, w));
+    vec3 v = cross(w, u);
+    auto viewport_u = viewport_width * u;   // double -> float at the call
+    auto viewport_v = viewport_height * -v;
+    vec3 pixel_delta_u = viewport_u / image_width;
+    vec3 pixel_delta_v = viewport_v / image_height;
+    auto viewport_upper_left = center - (focus_dist * w) - viewport_u / 2 - viewport_v / 2;
+    vec3 pixel00_loc = viewport_upper_left + 0.5 * (pixel_delta_u + pixel_delta_v);
+    auto defocus_radius = focus_dist * std::tan(degrees_to_radians(c.defocus_angle / 2));
+    vec3 defocus_disk_u = u * defocus_radius;
+    vec3 defocus_disk_v = v * defocus_radius;
+    o.image_width = image_width; o.image_height = image_height; o.pixel_samples_scale = pixel_samples_scale;
+    put(o.center, center); put(o.pixel00_loc, pixel00_loc);
+    put(o.pixel_delta_u, pixel_delta_u); put(o.pixel_delta_v, pixel_delta_v);
+    put(o.defocus_disk_u, defocus_disk_u); put(o.defocus_disk_v, defocus_disk_v);
+    o.defocus_angle = c.defocus_angle;
+}
+
+// render_with_cuda.h:6-29.  Block 0 of the sample: x_offset, y_offset, time <- lanes 0..2;
+// the disk is sampled from the following block(s), always (D14).
+ray get_ray(sample_stream& rs, const camera_derived& cam, int pixel_x, int pixel_y) {
+    f4 b = rs.next_block();
+    float x_offset = b.x - 0.5f;
+    float y_offset = b.y - 0.5f;
+    auto pixel_sample = get(cam.pixel00_loc) + ((pixel_x + x_offset) * get(cam.pixel_delta_u))
+                        + ((pixel_y + y_offset) * get(cam.pixel_delta_v));
+    auto p = random_in_unit_disk(rs);
+    auto p_in_disk = get(cam.center) + p.x() * get(cam.defocus_disk_u) + p.y() * get(cam.defocus_disk_v);
+    auto ray_origin = (cam.defocus_angle <= 0) ? get(cam.center) : p_in_disk;
+    auto ray_direction = pixel_sample - ray_origin;
+    auto ray_time = 1 - b.z;  // random_float
+    return ray(ray_origin, ray_direction, ray_time);
+}
+
+// render_with_cuda.h:31-56 / helper_experimental.h:52-78.  max_iter is 50 in the
+// reference; BASELINE config 1 asks for 10, so it is a parameter (D13).  The sky term
+// uses the PRIMARY ray r (D2, as written).
+color ray_color(sample_stream& rs, const ray& r, const scene& world, int max_iter, counters& ct) {
+    color attenuation_mult = vec3(1, 1, 1);
+    ray current_ray = r;
+    hit_record rec;
+    ray scattered;
+    color attenuation;
+    for (int i = 0; i < max_iter; i++) {
+        ct.rays++;
+        bool h = world.nodes ? external_hit(world, current_ray, interval(0.001, infinity), rec, ct)
+                             : list_hit(world, current_ray, interval(0.001, infinity), rec, ct);
+        if (h) {
+            if (scatter(world.materials[rec.mat], rs, current_ray, rec, attenuation, scattered)) {
+                attenuation_mult *= attenuation;
+                current_ray = scattered;
+            } else {
+                return color(0, 0, 0);
+            }
+        } else {
+            vec3 unit_direction = unit_vector(r.direction());
+            float a = 0.5f * (unit_direction.y() + 1.0f);
+            return attenuation_mult * ((1.0f - a) * color(1.0, 1.0, 1.0) + a * color(0.5, 0.7, 1.0));
+        }
+    }
+    return color(0, 0, 0);
+}
+
+scene make_scene(int n, const float* center, const float* motion, const float* radius, const int* mat_id,
+                 int m, const int* mtype, const float* malbedo, const float* mparam) {
+    scene s;
+    s.objects.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        vec3 mo = get(motion + 3 * i);
+        bool moving = !(mo.x() == 0 && mo.y() == 0 && mo.z() == 0);
+        s.objects.emplace_back(get(center + 3 * i), mo, radius[i], mat_id[i], moving);
+    }
+    for (int i = 0; i < m; ++i) s.materials.push_back(material{mtype[i], get(malbedo + 3 * i), mparam[i]});
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// BVH build: bvh.h:135-192 (ctor), :251-274 (sort recursion), :64-100 (create_bvh).
+
+// thrust::default_random_engine = minstd_rand: x <- 48271 x mod (2^31-1)
+// (thrust/random/linear_congruential_engine.h); uniform_int_distribution<int>(0,2) maps
+// int( double(x - 1) / 2147483646.0 * 3.0 ) (thrust/random/detail/uniform_int_distribution.inl,
+// uniform_real_distribution.inl).  Pinned against rocThrust in oracle/pin/.
+struct thrust_axis_rng {
+    uint32_t x;
+    explicit thrust_axis_rng(uint32_t seed) : x(seed % 2147483647u) { if (x == 0) x = 1; }
+    int operator()() {
+        x = (uint32_t)(((uint64_t)x * 48271u) % 2147483647u);
+        double result = double(x - 1u);
+        result /= (double(2147483646u - 1u) + 1.0);
+        return int((result * (3.0 - 0.0)) + 0.0);
+    }
+};
+
+struct bvh_primitive { size_t object_index; aabb bbox; };
+
+void sort_primitives_recursive(std::vector<bvh_primitive>& prims, thrust_axis_rng& rng, int start, int end) {
+    int axis = rng();  // drawn at EVERY call, before the span check (D7)
+    int object_span = end - start;
+    if (object_span >= 2) {
+        // primitive_comparator (bvh.h:30-45) is "<=", not a strict weak order; the tie
+        // rule is defined as strict "<" + stable = original order among equal keys (D3).
+        std::stable_sort(prims.begin() + start, prims.begin() + end,
+                         [axis](const bvh_primitive& a, const bvh_primitive& b) {
+                             return a.bbox.axis_interval(axis).min < b.bbox.axis_interval(axis).min;
+                         });
+        auto mid = start + object_span / 2;  // D8: split of the recursion, not of the tree
+        sort_primitives_recursive(prims, rng, start, mid);
+        sort_primitives_recursive(prims, rng, mid, end);
+    }
+}
+
+int bvh_tree_depth(int n) { return (int)ceil(log2((double)n)); }  // bvh.h:139
+
+void set_node(bvh_node& d, const aabb& b, int loc, int l, int r) {
+    d.xmin = b.x.min; d.xmax = b.x.max; d.ymin = b.y.min; d.ymax = b.y.max; d.zmin = b.z.min; d.zmax = b.z.max;
+    d.loc_for_leaf = loc; d.left_child_loc = l; d.right_child_loc = r;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    u32x4 r = philox4x32_10(u32x4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+float orc_u01(uint32_t v) { return u01(v); }
+
+// first `count` uniforms of the render stream (pixel, sample), block after block
+void orc_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, int nblocks, float* out) {
+    sample_stream rs(seed, pixel, sample);
+    for (int i = 0; i < nblocks; ++i) { f4 b = rs.next_block(); out[4 * i] = b.x; out[4 * i + 1] = b.y; out[4 * i + 2] = b.z; out[4 * i + 3] = b.w; }
+}
+
+// first `count` uniforms (curand_uniform convention, (0,1]) of the scene stream
+void orc_seq_stream(uint64_t seed, int count, float* out) {
+    seq_stream s(seed);
+    for (int i = 0; i < count; ++i) out[i] = s.curand_uniform();
+}
+
+void orc_axis_sequence(uint32_t seed, int count, int* out) {
+    thrust_axis_rng rng(seed);
+    for (int i = 0; i < count; ++i) out[i] = rng();
+}
+
+void orc_camera_initialize(const camera_params* p, camera_derived* out) { camera_initialize(*p, *out); }
+
+// helper.h:14-31 (create_world) == main_experimental.cu:42-53.  Returns sphere count.
+int orc_scene_small(float* center, float* motion, float* radius, int* mat_id, int* mtype, float* malbedo, float* mparam) {
+    const float c[5][3] = {{0.0, -100.5, -1.0}, {0.0, 0.0, -1.2}, {-1.0, 0.0, -1.0}, {-1.0, 0.0, -1.0}, {1.0, 0.0, -1.0}};
+    const float r[5] = {100.0, 0.5, 0.5, 0.4, 0.5};
+    const int t[5] = {0, 0, 2, 2, 1};
+    const float a[5][3] = {{0.8, 0.2, 0.2}, {0.1, 0.2, 0.5}, {1, 1, 1}, {1, 1, 1}, {0.7, 0.7, 0.7}};
+    const float p[5] = {0, 0, 1.50, (float)(1.00 / 1.50), 0.2};
+    for (int i = 0; i < 5; ++i) {
+        for (int k = 0; k < 3; ++k) { center[3 * i + k] = c[i][k]; motion[3 * i + k] = 0; malbedo[3 * i + k] = a[i][k]; }
+        radius[i] = r[i]; mat_id[i] = i; mtype[i] = t[i]; mparam[i] = p[i];
+    }
+    return 5;
+}
+
+// helper.h:37-102 (create_world2) generalised to a (2*half)x(2*half) grid; half = 11 is
+// the reference scene.  Capacity needed: 4 + 4*half*half.  `ground_radius` is 1000 in
+// the reference.  The reference seeds XORWOW with 18 (helper.h:41); here `seed` keys
+// the Philox scene stream (tag 1).
+int orc_scene_random(uint64_t seed, int half, float ground_radius, float* center, float* motion, float* radius,
+                     int* mat_id, int* mtype, float* malbedo, float* mparam) {
+    seq_stream rand_state(seed);
+    int counter = 0;
+    auto add = [&](const point3& c, const vec3& mo, float r, int type, const color& alb, float prm) {
+        put(center + 3 * counter, c); put(motion + 3 * counter, mo); radius[counter] = r; mat_id[counter] = counter;
+        mtype[counter] = type; put(malbedo + 3 * counter, alb); mparam[counter] = prm; counter++;
+    };
+    add(point3(0, -ground_radius, 0), vec3(0, 0, 0), ground_radius, 0, color(0.5, 0.5, 0.5), 0);
+    add(point3(0, 1, 0), vec3(0, 0, 0), 1.0, 2, color(1, 1, 1), 1.5);
+    add(point3(-4, 1, 0), vec3(0, 0, 0), 1.0, 0, color(0.4, 0.2, 0.1), 0);
+    add(point3(4, 1, 0), vec3(0, 0, 0), 1.0, 1, color(0.7, 0.6, 0.5), 0.0);
+    for (int a = -half; a < half; a++) {
+        for (int b = -half; b < half; b++) {
+            auto choose_mat = rand_state.random_float();
+            // braced init: evaluation order left to right is what the draw order needs
+            float cx = a + 0.9 * rand_state.random_float();
+            float cz = b + 0.9 * rand_state.random_float();
+            point3 c(cx, 0.2, cz);
+            if ((c - point3(4, 0.2, 0)).length() > 0.9) {
+                if (choose_mat < 0.8) {
+                    float r1 = rand_state.random_float(), g1 = rand_state.random_float(), b1 = rand_state.random_float();
+                    float r2 = rand_state.random_float(), g2 = rand_state.random_float(), b2 = rand_state.random_float();
+                    auto albedo = color(r1, g1, b1) * color(r2, g2, b2);
+                    auto center2 = c + vec3(0, rand_state.random_float(0, .5), 0);
+                    add(c, center2 - c, 0.2, 0, albedo, 0);  // sphere.h:19: center(center1, center2 - center1)
+                } else if (choose_mat < 0.95) {
+                    float r1 = rand_state.random_float(0.5, 1), g1 = rand_state.random_float(0.5, 1), b1 = rand_state.random_float(0.5, 1);
+                    auto fuzz = rand_state.random_float(0, 0.5);
+                    add(c, vec3(0, 0, 0), 0.2, 1, color(r1, g1, b1), fuzz < 1 ? fuzz : 1);
+                } else {
+                    add(c, vec3(0, 0, 0), 0.2, 2, color(1, 1, 1), 1.5);
+                }
+            }
+        }
+    }
+    return counter;
+}
+
+int orc_bvh_num_nodes(int n) {
+    if (n <= 0) return 0;
+    int depth = bvh_tree_depth(n);
+    return (int)pow(2, depth + 1) - 1;  // bvh.h:141
+}
+
+// Builds the reference's node array.  `leaf_order[i]` = object index stored in leaf i.
+int orc_bvh_build(int n, const float* center, const float* motion, const float* radius, uint32_t axis_seed,
+                  bvh_node* nodes, int* leaf_order) {
+    if (n <= 0) return 0;
+    std::vector<int> ids(n, 0), types(1, 0);
+    std::vector<float> alb(3, 0.f), prm(1, 0.f);
+    scene s = make_scene(n, center, motion, radius, ids.data(), 1, types.data(), alb.data(), prm.data());
+    std::vector<bvh_primitive> prims(n);
+    for (int i = 0; i < n; ++i) prims[i] = bvh_primitive{(size_t)i, s.objects[i].bbox};  // bvh.h:111-123
+    thrust_axis_rng rng(axis_seed);                                                     // bvh.h:144-147 (seed 17)
+    sort_primitives_recursive(prims, rng, 0, n);                                         // bvh.h:173
+    // create_bvh, bvh.h:64-100, level by level (D6)
+    int tree_depth = bvh_tree_depth(n);
+    const int num_leaves = (int)pow(2, tree_depth);
+    int curr_offset = num_leaves - 1;
+    for (int idx = 0; idx < num_leaves; ++idx) {
+        if (idx < n) set_node(nodes[curr_offset + idx], prims[idx].bbox, (int)prims[idx].object_index, -1, -1);
+        else set_node(nodes[curr_offset + idx], aabb(), -1, -1, -1);
+    }
+    int prev_offset = curr_offset;
+    for (int i = num_leaves / 2; i > 0; i /= 2) {
+        curr_offset -= i;
+        for (int idx = 0; idx < i; ++idx) {
+            int left_child = prev_offset + 2 * idx, right_child = prev_offset + 2 * idx + 1;
+            set_node(nodes[curr_offset + idx], aabb(node_box(nodes[left_child]), node_box(nodes[right_child])), -1,
+                     left_child, right_child);
+        }
+        prev_offset = curr_offset;
+    }
+    if (leaf_order) for (int i = 0; i < n; ++i) leaf_order[i] = (int)prims[i].object_index;
+    return 2 * num_leaves - 1;
+}
+
+// Un-normalised per-pixel sums over samples [s0, s0+ns) for the pixel rectangle
+// [x0,x1)x[y0,y1): sequential fp32 sum in sample order inside each chunk of `chunk`
+// samples (chunk<=0: one chunk), chunk sums added in chunk order.  `sums` is W*H*3 and is
+// ADDED to (caller zeroes).  stats[0..3] += rays, pair visits, sphere tests, samples.
+int orc_render(int n, const float* center, const float* motion, const float* radius, const int* mat_id,
+               int m, const int* mtype, const float* malbedo, const float* mparam,
+               const bvh_node* nodes, int num_nodes, const camera_derived* cam, uint64_t seed,
+               int x0, int y0, int x1, int y1, int s0, int ns, int chunk, int max_depth,
+               float* sums, uint64_t* stats, int nthreads) {
+    scene world = make_scene(n, center, motion, radius, mat_id, m, mtype, malbedo, mparam);
+    world.nodes = nodes; world.num_nodes = num_nodes;
+    const int W = cam->image_width;
+    if (chunk <= 0) chunk = ns > 0 ? ns : 1;
+    if (nthreads < 1) nthreads = 1;
+    std::atomic<int> next_row(y0);
+    std::vector<counters> cts(nthreads);
+    auto work = [&](int tid) {
+        counters& ct = cts[tid];
+        for (;;) {
+            int j = next_row.fetch_add(1);
+            if (j >= y1) break;
+            for (int i = x0; i < x1; ++i) {
+                uint32_t pixel_index = (uint32_t)(j * W + i);
+                float* px = sums + 3 * (size_t)pixel_index;
+                for (int c0 = 0; c0 < ns; c0 += chunk) {
+                    color part(0, 0, 0);
+                    int c1 = std::min(ns, c0 + chunk);
+                    for (int s = c0; s < c1; ++s) {
+                        sample_stream rs(seed, pixel_index, (uint32_t)(s0 + s));
+                        ray r = get_ray(rs, *cam, i, j);
+                        part += ray_color(rs, r, world, max_depth, ct);
+                        ct.samples++;
+                    }
+                    px[0] += part.x(); px[1] += part.y(); px[2] += part.z();
+                }
+            }
+        }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+        for (auto& t : th) t.join();
+    }
+    if (stats) for (auto& c : cts) { stats[0] += c.rays; stats[1] += c.pair_visits; stats[2] += c.sphere_tests; stats[3] += c.samples; }
+    return 0;
+}
+
+// One (pixel, sample): primary ray (7 floats: origin, direction, time), radiance (3), and
+// the number of closest-hit queries.  For fine-grained parity checks.
+int orc_trace_sample(int n, const float* center, const float* motion, const float* radius, const int* mat_id,
+                     int m, const int* mtype, const float* malbedo, const float* mparam,
+                     const bvh_node* nodes, int num_nodes, const camera_derived* cam, uint64_t seed,
+                     int px, int py, int sample, int max_depth, float* ray7, float* rgb, int* segments) {
+    scene world = make_scene(n, center, motion, radius, mat_id, m, mtype, malbedo, mparam);
+    world.nodes = nodes; world.num_nodes = num_nodes;
+    counters ct;
+    sample_stream rs(seed, (uint32_t)(py * cam->image_width + px), (uint32_t)sample);
+    ray r = get_ray(rs, *cam, px, py);
+    color c = ray_color(rs, r, world, max_depth, ct);
+    if (ray7) { put(ray7, r.orig); put(ray7 + 3, r.dir); ray7[6] = r.tm; }
+    put(rgb, c);
+    if (segments) *segments = (int)ct.rays;
+    return 0;
+}
+
+// Closest hit of one ray through list or BVH: returns hit flag, t and object index
+// (identified by material id == object id in the flat scenes; here by searching).
+int orc_closest_hit(int n, const float* center, const float* motion, const float* radius,
+                    const bvh_node* nodes, int num_nodes, const float* ray7, float* t_out, float* p_out, float* n_out) {
+    std::vector<int> ids(n), types(n, 0);
+    std::vector<float> alb(3 * (size_t)n, 0.f), prm(n, 0.f);
+    for (int i = 0; i < n; ++i) ids[i] = i;
+    scene world = make_scene(n, center, motion, radius, ids.data(), n, types.data(), alb.data(), prm.data());
+    world.nodes = nodes; world.num_nodes = num_nodes;
+    counters ct; hit_record rec;
+    ray r(get(ray7), get(ray7 + 3), ray7[6]);
+    bool h = nodes ? external_hit(world, r, interval(0.001, infinity), rec, ct) : list_hit(world, r, interval(0.001, infinity), rec, ct);
+    if (!h) return -1;
+    *t_out = rec.t; if (p_out) put(p_out, rec.p); if (n_out) put(n_out, rec.normal);
+    return rec.mat;
+}
+
+// color.h:9-35 + camera.h:44-57: P3 text PPM of a normalised framebuffer.  Returns the
+// number of bytes written (or needed, when buf is null).
+long orc_write_ppm(const float* fb, int width, int height, char* buf, long cap) {
+    long off = 0;
+    auto emit = [&](const char* s, int len) { if (buf && off + len <= cap) memcpy(buf + off, s, len); off += len; };
+    char tmp[64];
+    int len = snprintf(tmp, sizeof tmp, "P3\n%d %d\n255\n", width, height);
+    emit(tmp, len);
+    static const interval intensity(0.000, 0.999);
+    for (int j = 0; j < height; j++) {
+        for (int i = 0; i < width; i++) {
+            size_t pixel_index = (size_t)j * width + i;
+            float r = fb[3 * pixel_index], g = fb[3 * pixel_index + 1], b = fb[3 * pixel_index + 2];
+            auto gam = [](double lc) { return lc > 0 ? std::sqrt(lc) : 0.0; };
+            r = gam(r); g = gam(g); b = gam(b);  // float <- double sqrt, as color.h:18-25 (auto r is float)
+            int rbyte = int(256 * intensity.clamp(r));
+            int gbyte = int(256 * intensity.clamp(g));
+            int bbyte = int(256 * intensity.clamp(b));
+            len = snprintf(tmp, sizeof tmp, "%d %d %d\n", rbyte, gbyte, bbyte);
+            emit(tmp, len);
+        }
+    }
+    return off;
+}
+
+}  // extern "C"

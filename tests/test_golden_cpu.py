@@ -1,0 +1,34 @@
+"""The oracle against its own committed golden outputs (tests/golden/oracle_images.npz, written by
+tests/golden/make_golden.py): freezes rt_oracle.cpp bit for bit, on CPU."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_oracle_reproduces_golden(orc):
+    g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+    seed = int(g["seed"])
+    for name, sc, depth in (("small", orc.scene_small(), 10), ("random", orc.scene_random(18, 11), 50)):
+        nodes, order = orc.bvh_build(sc, 17)
+        assert np.array_equal(order, g[name + "_leaf_order"])
+        assert np.array_equal(orc.nodes_to_array(nodes), g[name + "_nodes"])
+        cam = orc.camera(64, 4)
+        a, _ = orc.render(sc, cam, seed, 0, 4, 0, depth, None)
+        b, st = orc.render(sc, cam, seed, 0, 4, 0, depth, nodes, nthreads=4)
+        scale = np.float32(0.25)
+        assert np.array_equal((a * scale).view(np.uint32), g[name + "_list"].view(np.uint32))
+        assert np.array_equal((b * scale).view(np.uint32), g[name + "_bvh"].view(np.uint32))
+        assert st == g[name + "_stats_bvh"].tolist()
+        # the BVH is only an acceleration structure: same image as the brute-force list
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert orc.scene_random(18, 11).n == int(g["random_n"])
+
+
+def test_product_host_bvh_matches_golden(crt):
+    g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+    for name, sc in (("small", crt.scene_small()), ("random", crt.scene_random(18, 11))):
+        nodes = crt.bvh_build_host(sc, 17)
+        got = np.frombuffer(bytes(nodes), np.uint32).reshape(-1, 9)
+        assert np.array_equal(got, g[name + "_nodes"])

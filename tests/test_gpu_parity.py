@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar: BIT-EXACT per path and per pixel sum -- the arithmetic contract (one IEEE rounding
+per fp32 operation, same Philox streams, same summation order) leaves no tolerance to state;
+where a tolerance applies (different summation order across GPU splits) it is written in the test.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def small(crt, orc):
+    return crt.scene_small(), orc.scene_small(), orc.bvh_build(orc.scene_small(), 17)[0]
+
+
+@pytest.fixture(scope="module")
+def rnd(crt, orc):
+    return crt.scene_random(18, 11), orc.scene_random(18, 11), orc.bvh_build(orc.scene_random(18, 11), 17)[0]
+
+
+def _renderer(crt, scene, cam, seed, bvh=True):
+    r = crt.Renderer(0, seed)
+    r.upload_scene(scene)
+    if bvh:
+        r.build_bvh(17)
+    r.set_camera(cam)
+    return r
+
+
+def test_bvh_readback_bit_exact(crt, orc, rnd, small):
+    for sc, osc, onodes in (rnd, small):
+        r = _renderer(crt, sc, crt.camera(64, 1), 1)
+        got = np.frombuffer(bytes(r.bvh_nodes()), np.uint32).reshape(-1, 9)
+        want = np.frombuffer(bytes(onodes), np.uint32).reshape(-1, 9)
+        assert np.array_equal(got, want)
+        r.close()
+
+
+@pytest.mark.parametrize("which,world", [("small", 0), ("small", 1), ("rnd", 0), ("rnd", 1)])
+def test_single_paths_bit_exact(crt, orc, small, rnd, which, world):
+    """Primary ray, radiance and segment count of individual (pixel, sample) paths."""
+    sc, osc, onodes = small if which == "small" else rnd
+    W, seed, depth = 400, 11, 50
+    cam, ocam = crt.camera(W, 10), orc.camera(W, 10)
+    r = _renderer(crt, sc, cam, seed)
+    rng = np.random.default_rng(5)
+    n = 300
+    px = rng.integers(0, W, n).astype(np.int32)
+    py = rng.integers(0, cam.image_height, n).astype(np.int32)
+    smp = rng.integers(0, 2000, n).astype(np.int32)
+    ray7, rgb, seg = r.trace_samples(world, px, py, smp, depth)
+    for i in range(n):
+        oray, orgb, oseg = orc.trace_sample(osc, ocam, seed, int(px[i]), int(py[i]), int(smp[i]), depth,
+                                            onodes if world else None)
+        assert _bits_equal(ray7[i], oray), i
+        assert _bits_equal(rgb[i], orgb), (i, rgb[i], orgb)
+        assert seg[i] == oseg, i
+    r.close()
+
+
+def test_config1_image_bit_exact(crt, orc, small):
+    """BASELINE config 1: 400x225, 10 spp, depth 10, 5 spheres, brute-force list -- the whole image."""
+    sc, osc, onodes = small
+    seed = 1
+    cam, ocam = crt.camera(400, 10), orc.camera(400, 10)
+    r = _renderer(crt, sc, cam, seed)
+    for world, nodes in ((crt.CRT_WORLD_LIST, None), (crt.CRT_WORLD_BVH, onodes)):
+        r.set_count_stats(True)
+        fb, st = r.render(world, 10, 0, 10)
+        sums, ost = orc.render(osc, ocam, seed, 0, 10, r.chunk_spp(10), 10, nodes, nthreads=8)
+        assert _bits_equal(fb, sums * np.float32(1.0 / 10))
+        assert [st.rays, st.pair_visits, st.sphere_tests, st.samples] == ost
+        r.set_count_stats(False)
+        fb2, st2 = r.render(world, 10, 0, 10)
+        assert _bits_equal(fb, fb2) and st2.rays == st.rays
+    r.close()
+
+
+def test_golden_fixture(crt):
+    """Committed oracle output (tests/golden/make_golden.py): 64x36, 4 spp, both scenes."""
+    g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+    for name, sc, depth in (("small", crt.scene_small(), 10), ("random", crt.scene_random(18, 11), 50)):
+        r = _renderer(crt, sc, crt.camera(64, 4), int(g["seed"]))
+        r.set_chunks(1)
+        fb_list, _ = r.render(crt.CRT_WORLD_LIST, 4, 0, depth)
+        fb_bvh, st = r.render(crt.CRT_WORLD_BVH, 4, 0, depth)
+        assert _bits_equal(fb_list, g[name + "_list"])
+        assert _bits_equal(fb_bvh, g[name + "_bvh"])
+        assert st.rays == int(g[name + "_rays"])
+        r.close()
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 2, 4, 8])
+def test_random_scene_chunked_sum_bit_exact(crt, orc, rnd, chunks):
+    """Random-spheres scene through the BVH, 67 spp so that chunks are ragged; every chunking."""
+    sc, osc, onodes = rnd
+    seed, W, spp = 5, 96, 67
+    cam, ocam = crt.camera(W, spp), orc.camera(W, spp)
+    r = _renderer(crt, sc, cam, seed)
+    r.set_chunks(chunks)
+    fb, st = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
+    sums, ost = orc.render(osc, ocam, seed, 0, spp, r.chunk_spp(spp), 50, onodes, nthreads=8)
+    assert _bits_equal(fb, sums * np.float32(1.0 / spp))
+    assert st.rays == ost[0] and st.samples == ost[3]
+    r.close()
+
+
+def test_sample_offset_split_and_accumulate(crt, orc, rnd):
+    """crt_render_accumulate: ranges add up -- the multi-GPU / progressive contract."""
+    import torch
+    sc, osc, onodes = rnd
+    seed, W = 9, 80
+    cam, ocam = crt.camera(W, 24), orc.camera(W, 24)
+    H = cam.image_height
+    r = _renderer(crt, sc, cam, seed)
+    r.set_chunks(1)
+    buf = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    r.render_accumulate(crt.CRT_WORLD_BVH, 0, 10, 50, buf.data_ptr(), stream)
+    r.render_accumulate(crt.CRT_WORLD_BVH, 10, 14, 50, buf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    a, _ = orc.render(osc, ocam, seed, 0, 10, 0, 50, onodes, nthreads=8)
+    b, _ = orc.render(osc, ocam, seed, 10, 14, 0, 50, onodes, nthreads=8)
+    assert _bits_equal(buf.cpu().numpy(), a + b)
+    # one pass over all 24 samples differs from the split only by fp32 summation order:
+    # |diff| <= 24 * 2^-24 * max partial sum  (stated tolerance)
+    whole, _ = r.render(crt.CRT_WORLD_BVH, 24, 0, 50)
+    split = buf.cpu().numpy() * np.float32(1.0 / 24)
+    tol = 24 * 2.0 ** -24 * float((a + b).max()) + 1e-12
+    assert np.max(np.abs(whole - split)) <= tol
+    r.close()
+
+
+def test_config2_full_size_region_and_properties(crt, orc, rnd):
+    """BASELINE config 2 geometry (1200x675, random spheres, BVH, depth 50): a band of rows
+    bit-exact against the oracle, plus size-independent properties on the full frame."""
+    sc, osc, onodes = rnd
+    seed, W, spp = 1, 1200, 4
+    cam, ocam = crt.camera(W, spp), orc.camera(W, spp)
+    assert cam.image_height == 675
+    r = _renderer(crt, sc, cam, seed)
+    fb, st = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
+    y0, y1 = 400, 416
+    sums, _ = orc.render(osc, ocam, seed, 0, spp, r.chunk_spp(spp), 50, onodes, region=(0, y0, W, y1), nthreads=8)
+    assert _bits_equal(fb[y0:y1], sums[y0:y1] * np.float32(1.0 / spp))
+    assert st.samples == 1200 * 675 * spp
+    assert np.all(np.isfinite(fb)) and fb.min() >= 0 and fb.max() <= 1.0 + 1e-5  # albedo <= 1, sky <= 1
+    fb2, st2 = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)   # idempotence / determinism
+    assert _bits_equal(fb, fb2) and st.rays == st2.rays
+    fb3, _ = r.render(crt.CRT_WORLD_LIST, spp, 0, 50)    # BVH == brute force on the full frame
+    assert _bits_equal(fb, fb3)
+    r.set_seed(2)
+    fb4, _ = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
+    assert not _bits_equal(fb, fb4)
+    # two independent 4-spp estimates of the same image agree statistically (PSNR bound, low spp)
+    mse = float(np.mean((fb.astype(np.float64) - fb4) ** 2))
+    assert 10 * np.log10(1.0 / mse) > 12.0
+    r.close()
+
+
+def test_scene_in_global_memory_path(crt, orc):
+    """A scene too big for LDS (80x80 grid, ~6.3k spheres, 16383 nodes) takes the HBM path."""
+    sc, osc = crt.scene_random(4, 40), orc.scene_random(4, 40)
+    onodes, _ = orc.bvh_build(osc, 17)
+    assert sc.n * 32 + 64 * 8192 > 64 * 1024
+    seed, W, spp = 3, 64, 3
+    cam = crt.camera(W, spp, lookfrom=(26, 4, 6))
+    ocam = orc.camera(W, spp, lookfrom=(26, 4, 6))
+    r = _renderer(crt, sc, cam, seed)
+    r.set_count_stats(True)
+    fb, st = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
+    sums, ost = orc.render(osc, ocam, seed, 0, spp, r.chunk_spp(spp), 50, onodes, nthreads=8)
+    assert _bits_equal(fb, sums * np.float32(1.0 / spp))
+    assert [st.rays, st.pair_visits, st.sphere_tests, st.samples] == ost
+    r.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_tiny_scenes(crt, orc, n):
+    """Single-sphere world (the root is a leaf), two and three spheres (padding leaf)."""
+    full_c, full_o = crt.scene_small(), orc.scene_small()
+
+    def cut(mod, s):
+        return mod.Scene(s.center[1:1 + n], s.motion[1:1 + n], s.radius[1:1 + n], np.arange(n, dtype=np.int32),
+                         s.mat_type[1:1 + n], s.mat_albedo[1:1 + n], s.mat_param[1:1 + n])
+    sc, osc = cut(crt, full_c), cut(orc, full_o)
+    onodes, _ = orc.bvh_build(osc, 17)
+    cam = crt.camera(48, 5, vfov=40.0, lookfrom=(0, 0.3, 3), lookat=(0, 0, -1), defocus_angle=0.0)
+    ocam = orc.camera(48, 5, vfov=40.0, lookfrom=(0, 0.3, 3), lookat=(0, 0, -1), defocus_angle=0.0)
+    r = _renderer(crt, sc, cam, 2)
+    for world, nodes in ((1, onodes), (0, None)):
+        fb, st = r.render(world, 5, 0, 50)
+        sums, ost = orc.render(osc, ocam, 2, 0, 5, r.chunk_spp(5), 50, nodes)
+        assert _bits_equal(fb, sums * np.float32(0.2))
+        assert st.rays == ost[0]
+    r.close()
+
+
+def test_error_behaviour(crt):
+    lib = crt.lib()
+    r = crt.Renderer(0, 1)
+    fb = np.zeros((4, 4, 3), np.float32)
+    st = crt.RenderStats()
+    fp = C.POINTER(C.c_float)
+    assert lib.crt_render(r._ctx, 1, 1, 0, 10, fb.ctypes.data_as(fp), C.byref(st)) == 4  # no camera
+    r.set_camera(crt.camera(4, 1))
+    assert lib.crt_render(r._ctx, 1, 1, 0, 10, fb.ctypes.data_as(fp), C.byref(st)) == 4  # no scene
+    assert b"scene" in lib.crt_last_error(r._ctx)
+    nn = C.c_int32()
+    assert lib.crt_build_bvh(r._ctx, 17, C.byref(nn)) == 4
+    r.upload_scene(crt.scene_small())
+    assert lib.crt_render(r._ctx, 1, 1, 0, 10, fb.ctypes.data_as(fp), C.byref(st)) == 4  # BVH not built
+    assert lib.crt_render(r._ctx, 0, 0, 0, 10, fb.ctypes.data_as(fp), C.byref(st)) == 1  # spp 0
+    assert lib.crt_render(r._ctx, 7, 1, 0, 10, fb.ctypes.data_as(fp), C.byref(st)) == 1  # bad world
+    assert lib.crt_set_chunks(r._ctx, 3) == 1
+    bad = crt.scene_small()
+    bad.mat_id[2] = 9
+    with pytest.raises(crt.CrtError):
+        r.upload_scene(bad)
+    ctx = C.c_void_p()
+    assert lib.crt_create(999, 1, C.byref(ctx)) == 1
+    r.close()
