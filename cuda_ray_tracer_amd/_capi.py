@@ -51,6 +51,15 @@ def load(path=LIB_PATH):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so (SONAME libamdhip64.so.7,
+    # the same as /opt/rocm's).  Two copies in one process each open the GPU and the second one
+    # finds "no HIP GPUs".  Importing torch first makes libcrt_hip.so's DT_NEEDED libamdhip64.so.7
+    # resolve to the copy torch already loaded, so device pointers, streams and RCCL buffers are
+    # shared with torch.  Without torch the library binds to /opt/rocm's runtime (its RUNPATH).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
     lib.crt_last_error.restype = C.c_char_p

@@ -159,8 +159,14 @@ def test_config2_full_size_region_and_properties(crt, orc, rnd):
     assert np.all(np.isfinite(fb)) and fb.min() >= 0 and fb.max() <= 1.0 + 1e-5  # albedo <= 1, sky <= 1
     fb2, st2 = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)   # idempotence / determinism
     assert _bits_equal(fb, fb2) and st.rays == st2.rays
-    fb3, _ = r.render(crt.CRT_WORLD_LIST, spp, 0, 50)    # BVH == brute force on the full frame
-    assert _bits_equal(fb, fb3)
+    # BVH vs brute-force list on the full frame: the same image except where a path grazes a
+    # sphere within fp32 rounding of its box (the slab test and sphere::hit round differently).
+    # The oracle shows exactly the same effect (1 pixel of 810 000 at this seed); bound: 1e-5.
+    fb3, _ = r.render(crt.CRT_WORLD_LIST, spp, 0, 50)
+    lsums, _ = orc.render(osc, ocam, seed, 0, spp, r.chunk_spp(spp), 50, None, region=(0, y0, W, y1), nthreads=8)
+    assert _bits_equal(fb3[y0:y1], lsums[y0:y1] * np.float32(1.0 / spp))
+    differing = int((fb.view(np.uint32) != fb3.view(np.uint32)).any(axis=2).sum())
+    assert differing <= 1e-5 * W * 675, differing
     r.set_seed(2)
     fb4, _ = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
     assert not _bits_equal(fb, fb4)
