@@ -44,6 +44,7 @@ struct crt_context {
     int chunks = 0;  // 0 = auto
     bool count_stats = false;
     size_t lds_limit = 64 * 1024;
+    int sched = 1, leaf_num = 4, shade_num = 6, run_shift = 3;
 };
 
 namespace {
@@ -95,8 +96,13 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     ctx->device = device;
     ctx->seed = seed;
     if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 1024) ctx->block = v; }
-    if (hipMalloc((void**)&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess ||
+    if (const char* b = getenv("CRT_SCHED")) ctx->sched = atoi(b) != 0;
+    if (const char* b = getenv("CRT_RUN_SHIFT")) { int v = atoi(b); if (v >= 0 && v <= 6) ctx->run_shift = v; }
+    if (const char* b = getenv("CRT_LDS_LIMIT")) ctx->lds_limit = size_t(atol(b));
+    if (const char* b = getenv("CRT_LEAF_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->leaf_num = v; }
+    if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
+    if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
@@ -264,6 +270,7 @@ static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth,
     a.chunk_spp = (ns + a.chunks - 1) / a.chunks;
     a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
     a.max_depth = max_depth;
+    a.sched = ctx->sched; a.run_shift = ctx->run_shift; a.leaf_num = ctx->leaf_num; a.shade_num = ctx->shade_num;
     a.sums = d_sums;
     a.counters = ctx->d_counters;
     return CRT_OK;
@@ -282,12 +289,12 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     const int tiles_per_block = nw / a.chunks;
     const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
     const int grid = int((tiles + tiles_per_block - 1) / tiles_per_block);
-    size_t scene_bytes = 32 * size_t(ctx->n) + 16 * size_t(ctx->m) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
+    size_t scene_bytes = 32 * size_t(ctx->n) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
     const bool in_lds = scene_bytes <= ctx->lds_limit;
     size_t lds = in_lds ? scene_bytes : 0;
     const size_t red = a.chunks > 1 ? size_t(nw) * 3 * 64 * sizeof(float) : 0;
     if (lds < red) lds = red;
-    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, stream));
     CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, ctx->block, grid, lds, stream));
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, stream));
@@ -308,6 +315,15 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     stats->kernel_seconds = ms * 1e-3;
     stats->wall_seconds = ctx->wall_seconds;
     stats->rays = c[0]; stats->samples = c[1]; stats->pair_visits = c[2]; stats->sphere_tests = c[3];
+    return CRT_OK;
+}
+
+// not part of the public header: scheduler census of the last counting launch (tools/tune.py)
+int crt_debug_counters(crt_context* ctx, uint64_t* out16) {
+    if (!ctx || !out16) return CRT_ERR_INVALID_ARGUMENT;
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

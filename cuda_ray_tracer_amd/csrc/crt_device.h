@@ -48,6 +48,9 @@ struct crt_render_args {
     int chunks;      // chunks per workgroup (waves of one tile)
     int tiles_x, tiles_y;
     int max_depth;
+    int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
+    int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
+    int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
     float* sums;
     unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests
 };

@@ -6,8 +6,8 @@
 // (tiles per block) x (chunks per tile); chunk sums meet in LDS and are added to the
 // framebuffer in chunk order -- no atomics, the result is deterministic.
 //
-// The scene (child-pair BVH records, spheres, materials; <= 64 KB for the reference's
-// random-spheres scene) is staged into LDS once per workgroup; scenes that do not fit
+// The scene (child-pair BVH records and spheres; 48 KB for the reference's random-spheres
+// scene) is staged into LDS once per workgroup; scenes that do not fit
 // are read from HBM through L1/L2.
 //
 // Arithmetic contract: every fp32 operation is one IEEE rounding in the order the
@@ -151,6 +151,24 @@ __device__ __forceinline__ bool slab(float bx0, float bx1, float by0, float by1,
     lo = nr > lo ? nr : lo; hi = fr < hi ? fr : hi;
     // lo only grows and hi only shrinks, so "max <= min after some axis" == "at the end"
     return !(hi <= lo);
+}
+
+// The same test with v_min/v_max: identical decisions whenever no product is NaN, i.e. whenever the
+// three reciprocals are finite (then (b - o) * inv is finite or +-inf).  Rays with a non-finite
+// reciprocal (a zero or denormal direction component) take slab() above.
+__device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float by1, float bz0, float bz1, v3 o,
+                                          v3 inv, float lo, float hi) {
+    const float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
+    const float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
+    const float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+    lo = fmaxf(lo, fminf(tx0, tx1)); hi = fminf(hi, fmaxf(tx0, tx1));
+    lo = fmaxf(lo, fminf(ty0, ty1)); hi = fminf(hi, fmaxf(ty0, ty1));
+    lo = fmaxf(lo, fminf(tz0, tz1)); hi = fminf(hi, fmaxf(tz0, tz1));
+    return !(hi <= lo);
+}
+
+__device__ __forceinline__ bool finite3(v3 a) {
+    return (fabsf(a.x) < __builtin_huge_valf()) & (fabsf(a.y) < __builtin_huge_valf()) & (fabsf(a.z) < __builtin_huge_valf());
 }
 
 struct hit_t { float t; int obj; };
@@ -310,7 +328,149 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
+// Wave-scheduled BVH path tracer.  Every lane is a small state machine:
+//   RUN    walking internal nodes (one child-pair record per step),
+//   LEAF   holding one or two candidate spheres of a leaf-parent, waiting for the sphere phase,
+//   SHADE  traversal finished (or no path yet), waiting for hit record + scatter + next ray,
+//   DONE   all samples of the lane's chunk traced.
+// Each iteration the WAVE picks one phase to run (wave-uniform branch on ballot counts): the
+// sphere and shade phases are postponed until enough lanes wait for them, so their code is not
+// re-executed for one or two lanes on every traversal step.  A lane's own sequence of operations
+// is exactly external_hit / ray_color (helper_experimental.h:1-78): a lane never steps past a
+// pending sphere test, so visit order, intervals and results are those of the simple loop.
+enum { ST_RUN = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
+
+template <bool IN_LDS, bool COUNT>
+__device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const float4* pairs, const float4* spheres,
+                                                    const float4* mats, bool has_work, int px, int py,
+                                                    uint32_t pixel_index, int c0, int c1, v3& acc, uint32_t& n_rays,
+                                                    uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests) {
+    const float tmin = 0.001f;
+    const uint32_t leaf_parents = (uint32_t)a.num_leaves >> 1;
+    stream rs; rs.k0 = a.key0; rs.k1 = a.key1; rs.pixel = pixel_index; rs.sample = 0; rs.event = 0;
+    path_t p;
+    p.r.o = mk(0, 0, 0); p.r.d = mk(0, 0, 1); p.r.tm = 0; p.thr = mk(1, 1, 1); p.sky_a = 0; p.depth = 0;
+    v3 inv = mk(1, 1, 1);
+    float ray_a = 1.0f, best_t = __builtin_huge_valf();
+    int best_obj = -1, cand0 = -1, cand1 = -1;
+    uint32_t k = 1, pending = 0;
+    bool fresh = true, exact = false;
+    int s = c0;
+    int st = has_work ? ST_SHADE : ST_DONE;
+
+    for (;;) {
+        const unsigned long long m_run = __ballot(st == ST_RUN);
+        const unsigned long long m_leaf = __ballot(st == ST_LEAF);
+        const unsigned long long m_shade = __ballot(st == ST_SHADE);
+        const int n_run = __popcll(m_run), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade);
+        const int alive = n_run + n_leaf + n_shade;
+        if (alive == 0) break;
+        int phase;
+        if (n_leaf * 16 >= alive * a.leaf_num && n_leaf > 0) phase = ST_LEAF;
+        else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) phase = ST_SHADE;
+        else if (n_run > 0) phase = ST_RUN;
+        else phase = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
+        if (COUNT && (threadIdx.x & 63) == 0) {  // scheduler census: iterations and served lanes per phase
+            const int served = phase == ST_RUN ? n_run : phase == ST_LEAF ? n_leaf : n_shade;
+            atomicAdd(&a.counters[4 + 2 * phase], 1ull);
+            atomicAdd(&a.counters[5 + 2 * phase], (unsigned long long)served);
+        }
+
+        if (phase == ST_RUN) {
+            // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
+            const int leave_at = n_run - max(1, n_run >> a.run_shift);
+            for (;;) {
+                if (st == ST_RUN) {
+                    const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+                    const int tagL = __float_as_int(q3.x), tagR = __float_as_int(q3.y);
+                    if (COUNT) n_pairs += 1;
+                    bool hitL, hitR;
+                    if (__builtin_expect(exact, 0)) {
+                        hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
+                        hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
+                    } else {
+                        hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
+                        hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
+                    }
+                    hitL = hitL & (tagL != CRT_TAG_EMPTY);
+                    hitR = hitR & (tagR != CRT_TAG_EMPTY);
+                    // branch-free successor: descend (left first, right remembered), hold the leaf
+                    // candidates (left sphere first, then right), or pop the pending right sibling
+                    const bool both = hitL & hitR, any = hitL | hitR;
+                    const bool leafp = k >= leaf_parents;
+                    cand0 = hitL ? tagL : tagR;
+                    cand1 = both ? tagR : -1;
+                    const uint32_t up = (uint32_t)__builtin_ctz(pending | 0x80000000u);
+                    const uint32_t k_pop = (k >> up) ^ 1u, p_pop = (pending >> up) ^ 1u;
+                    const uint32_t k_down = 2u * k + (hitL ? 0u : 1u), p_down = (pending << 1) | (both ? 1u : 0u);
+                    const bool done = !any & (pending == 0);
+                    const bool hold = any & leafp;
+                    k = any ? (leafp ? k : k_down) : k_pop;
+                    pending = any ? (leafp ? pending : p_down) : p_pop;
+                    st = hold ? ST_LEAF : (done ? ST_SHADE : ST_RUN);
+                }
+                if (__popcll(__ballot(st == ST_RUN)) <= leave_at) break;
+            }
+        } else if (phase == ST_LEAF) {
+            if (st == ST_LEAF) {
+                {
+                    const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand0), p.r, ray_a, tmin, best_t);
+                    if (COUNT) n_tests += 1;
+                    if (root > 0.0f) { best_t = root; best_obj = cand0; }
+                }
+                if (cand1 >= 0) {
+                    const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand1), p.r, ray_a, tmin, best_t);
+                    if (COUNT) n_tests += 1;
+                    if (root > 0.0f) { best_t = root; best_obj = cand1; }
+                }
+                if (pending == 0) { st = ST_SHADE; }
+                else {
+                    const int up = __builtin_ctz(pending);
+                    k = (k >> up) ^ 1u;
+                    pending = (pending >> up) ^ 1u;
+                    st = ST_RUN;
+                }
+            }
+        } else {
+            if (st == ST_SHADE) {
+                if (!fresh) {
+                    ++n_rays;
+                    bool ended;
+                    v3 rad = mk(0.0f, 0.0f, 0.0f);
+                    if (best_obj >= 0) {
+                        const sphere_rec sp = load_sphere<IN_LDS>(spheres, best_obj);
+                        const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
+                        const bool cont = shade(p, rs, sp, mrec, best_t);
+                        ++p.depth;
+                        ended = !cont || (p.depth >= a.max_depth);
+                    } else {
+                        rad = sky(p);
+                        ended = true;
+                    }
+                    if (ended) { acc = acc + rad; ++n_samples; ++s; fresh = true; }
+                }
+                if (fresh) {
+                    if (s >= c1) st = ST_DONE;
+                    else { start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s)); fresh = false; }
+                }
+                if (st != ST_DONE) {  // begin external_hit for the new segment
+                    best_t = __builtin_huge_valf(); best_obj = -1;
+                    ray_a = len2(p.r.d);
+                    if (a.num_leaves == 1) {  // the root is the only leaf: no box is tested
+                        cand0 = __float_as_int(pairs[3].x); cand1 = -1; pending = 0; st = ST_LEAF;
+                    } else {
+                        inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
+                        exact = !finite3(inv);
+                        k = 1; pending = 0; st = ST_RUN;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, bool SCHED>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) {
     extern __shared__ float4 smem[];
     constexpr int NW = BLOCK / 64;
@@ -318,15 +478,15 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     const float4* spheres = (const float4*)a.spheres;
     const float4* mats = (const float4*)a.mats;
     if (IN_LDS) {
-        const int np = (WORLD == 1) ? 4 * a.num_leaves : 0, ns = 2 * a.n, nm = a.m;
+        // pairs + spheres in LDS (48 KB for the reference scene: three 512-thread workgroups per CU);
+        // material records are read once per ray and stay in HBM/L2
+        const int np = (WORLD == 1) ? 4 * a.num_leaves : 0, ns = 2 * a.n;
         float4* s_pairs = smem;
         float4* s_spheres = smem + np;
-        float4* s_mats = s_spheres + ns;
         for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
         for (int i = threadIdx.x; i < ns; i += BLOCK) s_spheres[i] = spheres[i];
-        for (int i = threadIdx.x; i < nm; i += BLOCK) s_mats[i] = mats[i];
         __syncthreads();
-        pairs = s_pairs; spheres = s_spheres; mats = s_mats;
+        pairs = s_pairs; spheres = s_spheres;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunks = a.chunks;  // power of two dividing NW
@@ -342,7 +502,10 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
 
     v3 acc = mk(0.0f, 0.0f, 0.0f);
     uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
-    if (valid && c0 < c1) {
+    if (WORLD == 1 && SCHED) {
+        trace_bvh_scheduled<IN_LDS, COUNT>(a, pairs, spheres, mats, valid && c0 < c1, px, py, pixel_index, c0, c1, acc,
+                                           n_rays, n_samples, n_pairs, n_tests);
+    } else if (valid && c0 < c1) {
         stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
         path_t p;
         int s = c0;
@@ -450,15 +613,21 @@ __global__ __launch_bounds__(64) void trace_samples_kernel(const crt_render_args
     segments[i] = segs;
 }
 
-template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
-hipError_t launch_one(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto k = render_kernel<WORLD, IN_LDS, COUNT, BLOCK>;
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, bool SCHED>
+hipError_t launch_sched(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
+    auto k = render_kernel<WORLD, IN_LDS, COUNT, BLOCK, SCHED>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
+hipError_t launch_one(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
+    if (WORLD == 1 && a.sched) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1)>(a, grid, lds_bytes, stream);
+    return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, false>(a, grid, lds_bytes, stream);
 }
 
 template <int WORLD, bool IN_LDS, bool COUNT>

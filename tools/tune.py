@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""A/B timing of render-kernel variants in ONE process (interleaved rounds, median and min).
+
+Each variant is a set of CRT_* environment knobs read by crt_create (block size, scheduler on/off,
+phase thresholds).  Workload: the bench scene at 1200x675, --spp samples, depth 50.
+    python tools/tune.py --spp 100 --rounds 3 "CRT_SCHED=0" "CRT_SCHED=1" "CRT_SCHED=1 CRT_LEAF_NUM=2"
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+import cuda_ray_tracer_amd as crt  # noqa: E402
+
+KNOBS = ("CRT_BLOCK", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT")
+
+
+def make(variant, args):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    for kv in variant.split():
+        k, v = kv.split("=")
+        os.environ[k] = v
+    r = crt.Renderer(0, 1)
+    sc = crt.scene_random(18, args.half)
+    r.upload_scene(sc)
+    r.build_bvh(17)
+    r.set_camera(crt.camera(args.width, args.spp, lookfrom=tuple(args.lookfrom)))
+    if args.chunks:
+        r.set_chunks(args.chunks)
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+")
+    ap.add_argument("--spp", type=int, default=100)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--half", type=int, default=11)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--census", action="store_true")
+    ap.add_argument("--lookfrom", type=float, nargs=3, default=[13, 2, 3])
+    args = ap.parse_args()
+    rs = [make(v, args) for v in args.variants]
+    buf = torch.zeros(args.width * args.width * 3, dtype=torch.float32, device="cuda:0")
+    times = [[] for _ in rs]
+    rays = [0] * len(rs)
+    ref = None
+    for rnd in range(args.rounds + 1):
+        for i, r in enumerate(rs):
+            buf.zero_()
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            st = r.stats()
+            if rnd:
+                times[i].append(st.kernel_seconds * 1e3)
+            rays[i] = st.rays
+            if rnd == 0:
+                chk = float(buf.double().sum())
+                if ref is None:
+                    ref = chk
+                print(f"# {args.variants[i]!r}: rays {st.rays} checksum {chk:.6f} {'OK' if chk == ref else 'DIFFERS'}", flush=True)
+    if args.census:
+        import ctypes as C
+        for i, r in enumerate(rs):
+            r.set_count_stats(True)
+            buf.zero_()
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            st = r.stats()
+            c = (C.c_uint64 * 16)()
+            crt.lib().crt_debug_counters(r._ctx, c)
+            c = list(c)
+            names = ["RUN", "LEAF", "SHADE"]
+            msg = " ".join(f"{names[j]}: iters {c[4 + 2 * j]} lanes/iter {c[5 + 2 * j] / max(1, c[4 + 2 * j]):.1f}" for j in range(3))
+            print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
+            r.set_count_stats(False)
+    for i, v in enumerate(args.variants):
+        med, mn = statistics.median(times[i]), min(times[i])
+        print(f"{v:48s} median {med:9.3f} ms  min {mn:9.3f} ms  {rays[i] / med / 1e3:9.1f} Mrays/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
