@@ -44,7 +44,7 @@ struct crt_context {
     int chunks = 0;  // 0 = auto
     bool count_stats = false;
     size_t lds_limit = 64 * 1024;
-    int sched = 1, leaf_num = 4, shade_num = 6, run_shift = 3;
+    int sched = 1, leaf_num = 4, shade_num = 6, run_shift = 1;
 };
 
 namespace {
