@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
+from cuda_ray_tracer_amd.multi_gpu import render_split, sample_range  # noqa: E402
 
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= the f32 MFMA dense peak)
 HBM_PEAK_GBS = 8000.0
@@ -94,20 +95,15 @@ def main():
     W, H = cam.image_width, cam.image_height
 
     # sample split: rank g traces samples [lo, hi) of every pixel
-    lo = rank * args.spp // world_size
-    hi = (rank + 1) * args.spp // world_size
+    lo, hi = sample_range(args.spp, world_size, rank)
     sums = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
-    scale = float(np.float32(1.0 / args.spp))
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        sums.zero_()
-        if hi > lo:
-            r.render_accumulate(crt.CRT_WORLD_BVH, lo, hi - lo, args.depth, sums.data_ptr(), stream)
-        if world_size > 1:
-            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-        if rank == 0:
-            sums.mul_(scale)
+    def trace_range(first, count, buf):
+        r.render_accumulate(crt.CRT_WORLD_BVH, first, count, args.depth, buf.data_ptr(), stream)
+
+    def step():  # zero, trace this rank's samples, RCCL reduce(SUM) to rank 0, scale by 1/spp
+        render_split(trace_range, sums, args.spp, world_size, rank)
 
     def sync():
         if world_size > 1:
@@ -121,8 +117,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if args.steps <= 64:
-            pass
     torch.cuda.synchronize()
     if world_size > 1:
         dist.barrier()
@@ -131,15 +125,10 @@ def main():
     st = r.stats() if hi > lo else None  # last launch: rays of one step on this rank (identical every step)
     rays_rank = float(st.rays) if st else 0.0
     samples_rank = float(st.samples) if st else 0.0
-
-    # per-launch kernel time, HIP events on the launch stream, measured over the timed region:
-    # a second timed loop would double the run, so the events of every timed step are read here
-    # by re-running K steps with a stats read after each (outside the wall-clock region).
-    for _ in range(args.steps):
-        step()
-        if hi > lo:
-            kernel_s.append(r.stats().kernel_seconds)
-    sync()
+    # per-launch kernel time of the TIMED steps: HIP events the library records on the launch
+    # stream around every launch (it keeps the last 64)
+    if hi > lo:
+        kernel_s = r.kernel_times(min(args.steps, 64))
 
     t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device=dev)
     if world_size > 1:

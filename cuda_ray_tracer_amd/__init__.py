@@ -197,6 +197,11 @@ class Renderer:
         _check(lib().crt_get_stats(self._ctx, C.byref(st)), "crt_get_stats", self._ctx)
         return st
 
+    def kernel_times(self, count):
+        out = (C.c_double * count)()
+        _check(lib().crt_get_kernel_times(self._ctx, count, out), "crt_get_kernel_times", self._ctx)
+        return list(out)
+
     def trace_samples(self, world, px, py, sample, max_depth=50):
         px = np.ascontiguousarray(px, np.int32)
         py = np.ascontiguousarray(py, np.int32)

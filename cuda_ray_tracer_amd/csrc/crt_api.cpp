@@ -36,13 +36,16 @@ struct crt_context {
     int *d_px = nullptr, *d_py = nullptr, *d_smp = nullptr, *d_seg = nullptr;
     float *d_ray7 = nullptr, *d_rgb = nullptr;
     int dbg_cap = 0;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    static constexpr int EV_RING = 64;  // event pairs of the most recent launches
+    hipEvent_t ev_ring[2 * EV_RING] = {};
+    long launches = 0;
     bool launched = false;
     double wall_seconds = 0;
     // tuning
     int block = 512;
     int chunks = 0;  // 0 = auto
     bool count_stats = false;
+    bool census = false;
     size_t lds_limit = 64 * 1024;
     int sched = 1, leaf_num = 4, shade_num = 6, run_shift = 1;
 };
@@ -103,10 +106,15 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
     if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        false) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
     }
+    for (hipEvent_t& e : ctx->ev_ring)
+        if (hipEventCreate(&e) != hipSuccess) {
+            crt_destroy(ctx);
+            return fail(nullptr, CRT_ERR_HIP, "crt_create: event creation failed");
+        }
     *out = ctx;
     return CRT_OK;
 }
@@ -118,8 +126,7 @@ int crt_destroy(crt_context* ctx) {
     void* bufs[] = {ctx->d_pairs, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_counters, ctx->d_px, ctx->d_py,
                     ctx->d_smp, ctx->d_seg, ctx->d_ray7, ctx->d_rgb};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    for (hipEvent_t e : ctx->ev_ring) if (e) (void)hipEventDestroy(e);
     delete ctx;
     return CRT_OK;
 }
@@ -141,6 +148,7 @@ int crt_set_chunks(crt_context* ctx, int32_t chunks) {
 int crt_set_count_stats(crt_context* ctx, int32_t enable) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     ctx->count_stats = enable != 0;
+    ctx->census = enable == 2;  // internal: scheduler census for tools/tune.py
     return CRT_OK;
 }
 
@@ -270,7 +278,7 @@ static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth,
     a.chunk_spp = (ns + a.chunks - 1) / a.chunks;
     a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
     a.max_depth = max_depth;
-    a.sched = ctx->sched; a.run_shift = ctx->run_shift; a.leaf_num = ctx->leaf_num; a.shade_num = ctx->shade_num;
+    a.sched = ctx->sched; a.census = ctx->census; a.run_shift = ctx->run_shift; a.leaf_num = ctx->leaf_num; a.shade_num = ctx->shade_num;
     a.sums = d_sums;
     a.counters = ctx->d_counters;
     return CRT_OK;
@@ -295,9 +303,11 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     const size_t red = a.chunks > 1 ? size_t(nw) * 3 * 64 * sizeof(float) : 0;
     if (lds < red) lds = red;
     CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
-    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, stream));
+    const int slot = int(ctx->launches % crt_context::EV_RING);
+    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
     CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, ctx->block, grid, lds, stream));
-    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, stream));
+    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
+    ctx->launches += 1;
     ctx->launched = true;
     return CRT_OK;
 }
@@ -307,14 +317,30 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     memset(stats, 0, sizeof *stats);
     if (!ctx->launched) return fail(ctx, CRT_ERR_STATE, "crt_get_stats: nothing launched yet");
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    const int slot = int((ctx->launches - 1) % crt_context::EV_RING);
+    CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
     float ms = 0;
-    CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
     unsigned long long c[4];
     CRT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     stats->kernel_seconds = ms * 1e-3;
     stats->wall_seconds = ctx->wall_seconds;
     stats->rays = c[0]; stats->samples = c[1]; stats->pair_visits = c[2]; stats->sphere_tests = c[3];
+    return CRT_OK;
+}
+
+int crt_get_kernel_times(crt_context* ctx, int32_t count, double* seconds_out) {
+    if (!ctx || !seconds_out || count < 1) return CRT_ERR_INVALID_ARGUMENT;
+    if (count > crt_context::EV_RING || count > ctx->launches)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_get_kernel_times: more launches asked for than recorded (ring of 64)");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < count; ++i) {  // oldest of the `count` most recent launches first
+        const int slot = int((ctx->launches - count + i) % crt_context::EV_RING);
+        CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
+        float ms = 0;
+        CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+        seconds_out[i] = ms * 1e-3;
+    }
     return CRT_OK;
 }
 

@@ -49,6 +49,7 @@ struct crt_render_args {
     int tiles_x, tiles_y;
     int max_depth;
     int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
+    int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
     int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
     int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
     float* sums;

@@ -370,7 +370,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) phase = ST_SHADE;
         else if (n_run > 0) phase = ST_RUN;
         else phase = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
-        if (COUNT && (threadIdx.x & 63) == 0) {  // scheduler census: iterations and served lanes per phase
+        if (COUNT && a.census && (threadIdx.x & 63) == 0) {  // scheduler census: iterations and served lanes per phase
             const int served = phase == ST_RUN ? n_run : phase == ST_LEAF ? n_leaf : n_shade;
             atomicAdd(&a.counters[4 + 2 * phase], 1ull);
             atomicAdd(&a.counters[5 + 2 * phase], (unsigned long long)served);

@@ -1,0 +1,198 @@
+// rt_scene.h -- host-side scene classes with the reference's names and constructors:
+//   material / lambertian / metal / dielectric / material_list   (material.h:7-115)
+//   hit_record / hittable / sphere / hittable_list               (hittable.h, sphere.h, hittable_list.h)
+//   bvh_node / bvh_world                                          (bvh.h:47-62, :126-192)
+// In the reference these objects live in device memory and are called through device-side
+// virtuals.  Here they are plain host objects that FLATTEN into the SoA arrays of
+// crt_upload_scene; intersection and scattering run in libcrt_hip.so.
+#ifndef CRT_HOST_RT_SCENE_H
+#define CRT_HOST_RT_SCENE_H
+
+#include <cmath>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "rt_math.h"
+
+class material;
+
+// hittable.h:8-23 -- kept for source compatibility; filled by the GPU, not by host code
+class hit_record {
+  public:
+    point3 p;
+    vec3 normal;
+    material* mat_ptr = nullptr;
+    float t = 0;
+    bool front_face = false;
+};
+
+// what a material flattens to (crt_upload_scene: type, albedo, param)
+struct crt_flat_material {
+    int32_t type;
+    color albedo;
+    float param;
+};
+
+class material {  // material.h:7-20
+  public:
+    virtual ~material() = default;
+    // a material of the base class never scatters (material.h:11-19): the path returns black.
+    // It flattens to a lambertian of albedo 0, whose paths carry zero radiance as well.
+    virtual crt_flat_material flatten() const { return {CRT_LAMBERTIAN, color(0, 0, 0), 0.0f}; }
+};
+
+class lambertian : public material {  // material.h:22-42
+  public:
+    lambertian(const color& albedo) : albedo(albedo) {}
+    crt_flat_material flatten() const override { return {CRT_LAMBERTIAN, albedo, 0.0f}; }
+
+  private:
+    color albedo;
+};
+
+class metal : public material {  // material.h:44-60
+  public:
+    metal(const color& albedo, float fuzz) : albedo(albedo), fuzz(fuzz < 1 ? fuzz : 1) {}
+    crt_flat_material flatten() const override { return {CRT_METAL, albedo, fuzz}; }
+
+  private:
+    color albedo;
+    float fuzz;
+};
+
+class dielectric : public material {  // material.h:62-98
+  public:
+    dielectric(float refraction_index) : refraction_index(refraction_index) {}
+    crt_flat_material flatten() const override { return {CRT_DIELECTRIC, color(1, 1, 1), refraction_index}; }
+
+  private:
+    float refraction_index;
+};
+
+class material_list {  // material.h:100-115: owner of the materials
+  public:
+    material** materials;
+    int size;
+    material_list(material** material_list_list, int length) : materials(material_list_list), size(length) {}
+    ~material_list() {
+        for (int i = 0; i < size; ++i) delete materials[i];
+        delete[] materials;
+    }
+};
+
+// flattened scene under construction
+struct crt_flat_scene {
+    std::vector<float> center, motion, radius, mat_albedo, mat_param;
+    std::vector<int32_t> mat_id, mat_type;
+    std::unordered_map<const material*, int32_t> mat_ptrs;  // one flat material per distinct pointer
+    int32_t material_index(const material* m) {
+        auto it = mat_ptrs.find(m);
+        if (it != mat_ptrs.end()) return it->second;
+        const crt_flat_material f = m->flatten();
+        const int32_t id = int32_t(mat_type.size());
+        mat_ptrs.emplace(m, id);
+        mat_type.push_back(f.type);
+        for (int k = 0; k < 3; ++k) mat_albedo.push_back(f.albedo[k]);
+        mat_param.push_back(f.param);
+        return id;
+    }
+    int32_t num_objects() const { return int32_t(radius.size()); }
+};
+
+class hittable {  // hittable.h:43-51
+  public:
+    virtual ~hittable() = default;
+    virtual aabb bounding_box() const = 0;
+    virtual void flatten(crt_flat_scene& out) const = 0;  // replaces the device-side virtual hit()
+};
+
+class sphere : public hittable {  // sphere.h:6-42
+  public:
+    sphere(const point3& static_center, float radius, material* new_mat)
+        : center(static_center, vec3(0, 0, 0)), radius(fmaxf(0, radius)), mat_ptr(new_mat) {
+        const vec3 rvec(radius, radius, radius);
+        bbox = aabb(static_center - rvec, static_center + rvec);
+    }
+    sphere(const point3& center1, const point3& center2, float radius, material* new_mat)
+        : center(center1, center2 - center1), radius(fmaxf(0, radius)), mat_ptr(new_mat) {
+        const vec3 rvec(radius, radius, radius);
+        const aabb box1(center.at(0) - rvec, center.at(0) + rvec);
+        const aabb box2(center.at(1) - rvec, center.at(1) + rvec);
+        bbox = aabb(box1, box2);
+    }
+    // unlike sphere.h:28-29 the copy keeps its bounding box
+    sphere(const sphere& other) = default;
+
+    aabb bounding_box() const override { return bbox; }
+    void flatten(crt_flat_scene& out) const override {
+        for (int k = 0; k < 3; ++k) { out.center.push_back(center.orig[k]); out.motion.push_back(center.dir[k]); }
+        out.radius.push_back(radius);
+        out.mat_id.push_back(out.material_index(mat_ptr));
+    }
+
+    ray center;
+    float radius;
+    material* mat_ptr;
+    aabb bbox;
+};
+
+class hittable_list : public hittable {  // hittable_list.h:7-41
+  public:
+    hittable** objects;
+    int size;
+    hittable_list(hittable** object_list, int length) : objects(object_list), size(length) {
+        aabb box;
+        if (length > 0) {
+            box = object_list[0]->bounding_box();
+            for (int i = 1; i < length; ++i) box = aabb(box, object_list[i]->bounding_box());
+        }
+        bbox = box;
+    }
+    aabb bounding_box() const override { return bbox; }
+    void flatten(crt_flat_scene& out) const override {
+        for (int i = 0; i < size; ++i) objects[i]->flatten(out);
+    }
+
+  private:
+    aabb bbox;
+};
+
+// bvh.h:47-62 -- same fields, same 36-byte layout
+class bvh_node {
+  public:
+    aabb bbox;
+    int loc_for_leaf = -1;
+    int left_child_loc = -1;
+    int right_child_loc = -1;
+};
+static_assert(sizeof(bvh_node) == sizeof(crt_bvh_node), "bvh_node must match crt_bvh_node");
+
+// bvh.h:126-192.  The constructor flattens the objects, sorts and builds the node array with the
+// library's builder (bit-identical to the reference algorithm under the documented tie rule) and
+// keeps the nodes in host memory; render_experimental() hands the same scene to the GPU.
+class bvh_world {
+  public:
+    int num_objects;
+    hittable** d_objects;
+    int num_nodes;
+    bvh_node* d_nodes;
+    crt_flat_scene flat;
+
+    bvh_world(hittable** object_list, int list_length)
+        : num_objects(list_length), d_objects(object_list), num_nodes(0), d_nodes(nullptr) {
+        for (int i = 0; i < list_length; ++i) object_list[i]->flatten(flat);
+        num_nodes = crt_bvh_num_nodes(flat.num_objects());
+        if (num_nodes > 0) {
+            d_nodes = new bvh_node[num_nodes];
+            crt_bvh_build_host(flat.num_objects(), flat.center.data(), flat.motion.data(), flat.radius.data(), 17u,
+                               reinterpret_cast<crt_bvh_node*>(d_nodes));  // seed 17: bvh.h:144
+        }
+    }
+    ~bvh_world() { delete[] d_nodes; }  // bvh.h:194
+    bvh_world(const bvh_world&) = delete;
+    bvh_world& operator=(const bvh_world&) = delete;
+};
+
+#endif

@@ -148,8 +148,8 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam);
 
 /* render(), helper.h:111-171 (world = CRT_WORLD_LIST) and render_experimental(),
  * helper_experimental.h:148-213 (world = CRT_WORLD_BVH): traces samples
- * [sample_offset, sample_offset + cam.samples_per_pixel ... see `spp`) of every pixel and
- * writes the normalised framebuffer (sum * 1/spp) to the caller's host buffer.
+ * [sample_offset, sample_offset + spp) of every pixel and writes the normalised framebuffer
+ * (sum * 1/spp) to the caller's host buffer.
  * max_depth is the bounce limit (50 in render_with_cuda.h:33). */
 int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
                float* fb_host, crt_render_stats* stats);
@@ -163,6 +163,11 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
 
 /* Waits for the last launch and returns its statistics. */
 int crt_get_stats(crt_context* ctx, crt_render_stats* stats);
+
+/* Device time (HIP events recorded on the launch stream around each render launch) of the
+ * `count` most recent crt_render / crt_render_accumulate launches, oldest first; the library keeps
+ * the last 64.  Waits for those launches. */
+int crt_get_kernel_times(crt_context* ctx, int32_t count, double* seconds_out);
 
 /* Summation contract: per pixel the samples of one call are summed in fp32 sequentially
  * in sample order inside chunks of crt_chunk_spp() consecutive samples, and the chunk

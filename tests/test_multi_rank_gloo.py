@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: two gloo ranks split the samples exactly as bench.py does on GPUs
+(cuda_ray_tracer_amd.multi_gpu), with the oracle standing in for the device kernel, and the reduced
+image must equal the single-rank image of the same sample ranges."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world_size, port, spp, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    import oracle_lib as orc
+    from cuda_ray_tracer_amd.multi_gpu import render_split
+    sc = orc.scene_small()
+    cam = orc.camera(48, spp)
+    sums = torch.zeros(cam.image_height, cam.image_width, 3, dtype=torch.float32)
+
+    def trace_range(first, count, buf):
+        part, _ = orc.render(sc, cam, 7, first, count, 0, 10)
+        buf += torch.from_numpy(part)
+
+    render_split(trace_range, sums, spp, world_size, rank)
+    if rank == 0:
+        np.save(out_path, sums.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,spp", [(2, 9), (3, 8), (2, 1)])
+def test_sample_split_reduce(tmp_path, world_size, spp):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from cuda_ray_tracer_amd.multi_gpu import sample_range
+    ranges = [sample_range(spp, world_size, r) for r in range(world_size)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == spp
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world_size - 1))
+    out = str(tmp_path / "img.npy")
+    port = 29500 + os.getpid() % 2000 + world_size
+    mp.spawn(_worker, args=(world_size, port, spp, out), nprocs=world_size, join=True)
+    got = np.load(out)
+    sc, cam = orc.scene_small(), orc.camera(48, spp)
+    parts = [orc.render(sc, cam, 7, lo, hi - lo, 0, 10)[0] for lo, hi in ranges if hi > lo]
+    scale = np.float32(1.0 / spp)
+    if len(parts) <= 2:  # a + b is exact in any order
+        want = sum(parts[1:], parts[0]) * scale
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:  # reduction order of > 2 ranks is the collective's: tolerance = ranks * 2^-24 * max sum
+        want = sum(parts[1:], parts[0]) * scale
+        tol = world_size * 2.0 ** -24 * float(sum(parts).max()) * float(scale) + 1e-12
+        assert np.max(np.abs(got - want)) <= tol
+    # and the split image is the same estimator as the unsplit one (same paths, other summation order)
+    whole, _ = orc.render(sc, cam, 7, 0, spp, 0, 10)
+    assert np.max(np.abs(got - whole * scale)) <= spp * 2.0 ** -23 * float(whole.max()) * float(scale) + 1e-12

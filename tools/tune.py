@@ -67,7 +67,7 @@ def main():
     if args.census:
         import ctypes as C
         for i, r in enumerate(rs):
-            r.set_count_stats(True)
+            r.set_count_stats(2)
             buf.zero_()
             r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
             st = r.stats()
