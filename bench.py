@@ -46,7 +46,7 @@ def cpu_baseline(args, seed):
     t0 = time.perf_counter()
     _, st = orc.render(sc, cam, seed, 0, 1, 0, args.depth, nodes, nthreads=threads)
     t1 = time.perf_counter() - t0
-    spp = int(max(1, min(16, args.cpu_seconds / max(t1, 1e-3))))
+    spp = int(max(1, min(128, args.cpu_seconds / max(t1, 1e-3))))
     t0 = time.perf_counter()
     _, st = orc.render(sc, cam, seed, 1, spp, 0, args.depth, nodes, nthreads=threads)
     dt = time.perf_counter() - t0
@@ -155,11 +155,11 @@ def main():
         roofline = {
             "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tflops / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-            "kernel": "render_kernel<BVH, scene in LDS>", "kernel_ms": kavg * 1e3,
+            "kernel": "render_kernel<WORLD=BVH, IN_LDS, COUNT=0, BLOCK=512, SCHED=1>", "kernel_ms": kavg * 1e3,
             "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
             "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
             "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
-            "note": "not a dense contraction (no MFMA) and the 55 KB scene is LDS-resident (HBM traffic ~0): "
+            "note": "not a dense contraction (no MFMA) and the 48 KB scene (child-pair records + spheres) is LDS-resident (HBM traffic ~0): "
                     "the bound is fp32 VALU issue under wave64 divergence; peak = 157.3 TFLOP/s fp32 vector "
                     "(= the f32-input MFMA dense peak); scene_fetch_GBs is the algorithmic LDS fetch rate",
         }
