@@ -70,7 +70,16 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scene-seed", type=int, default=18)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 = BASELINE configs[1] (the metric's config, default); c4 = configs[3], the synthetic "
+                         "1M-sphere HBM stress (1920x1080, 64 spp) -- a DESIGN.md measurement, not the driver's line")
     args = ap.parse_args()
+    half, ground, cam_kw = 11, 1000.0, {}
+    if args.config == "c4":  # the same generator on a 1000x1000 grid, camera pulled back 40x
+        half, ground = 500, 1.0e5
+        cam_kw = dict(lookfrom=(520.0, 80.0, 120.0), focus_dist=540.0)
+        if args.width == 1200 and args.spp == 500:
+            args.width, args.spp = 1920, 64
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,10 +94,10 @@ def main():
     # ---- set-up (also timed once as part of time-to-image) ----------------------------------
     t_setup0 = time.perf_counter()
     r = crt.Renderer(local_rank, args.seed)
-    scene = crt.scene_random(args.scene_seed, 11)
+    scene = crt.scene_random(args.scene_seed, half, ground)
     r.upload_scene(scene)
     num_nodes = r.build_bvh(17)
-    cam = crt.camera(args.width, args.spp)
+    cam = crt.camera(args.width, args.spp, **cam_kw)
     r.set_camera(cam)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup0
@@ -163,6 +172,15 @@ def main():
                     "the bound is fp32 VALU issue under wave64 divergence; peak = 157.3 TFLOP/s fp32 vector "
                     "(= the f32-input MFMA dense peak); scene_fetch_GBs is the algorithmic LDS fetch rate",
         }
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is
+        # the rocprofv3 FETCH_SIZE + WRITE_SIZE measurement of the same launch committed under profiles/
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[args.config]
+            if W == (1200 if args.config == "c2" else 1920) and world_size == 1:
+                roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_summary.txt"
+        except (OSError, KeyError, ValueError):
+            pass
         # time-to-image: set-up + one step + read-back of the finished frame
         t1 = time.perf_counter()
         step()
@@ -182,7 +200,15 @@ def main():
             "image_mean": float(img.mean()),
             "roofline": roofline,
         }
-        if world_size == 1 and args.cpu_seconds > 0:
+        if args.config == "c4":
+            out["config"]["workload"] = (f"synthetic {scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
+                                         f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
+            roofline.update({"bound": "hbm", "achieved": roofline["scene_fetch_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": roofline["scene_fetch_GBs"] / HBM_PEAK_GBS,
+                             "kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=512, SCHED=1>",
+                             "note": "scene (67 MB child-pair records + 32 MB spheres) is read from HBM/Infinity Cache by "
+                                     "random access; achieved = algorithmic bytes (64 I + 32 S per ray) / kernel time"})
+        if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(args, args.seed)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

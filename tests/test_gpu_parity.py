@@ -238,3 +238,23 @@ def test_error_behaviour(crt):
     ctx = C.c_void_p()
     assert lib.crt_create(999, 1, C.byref(ctx)) == 1
     r.close()
+
+
+def test_million_sphere_scene(crt, orc):
+    """BASELINE config 4 geometry: the generator on a 1000x1000 grid (10^6 spheres, 2 097 151 nodes,
+    scene in HBM).  BVH bit-exact against the oracle's literal recursion; a small frame bit-exact."""
+    sc, osc = crt.scene_random(18, 500, 1.0e5), orc.scene_random(18, 500, 1.0e5)
+    assert sc.n == osc.n and sc.n > 999000
+    onodes, _ = orc.bvh_build(osc, 17)
+    kw = dict(lookfrom=(520.0, 80.0, 120.0), focus_dist=540.0)
+    seed, W, spp = 4, 64, 2
+    cam, ocam = crt.camera(W, spp, **kw), orc.camera(W, spp, **kw)
+    r = _renderer(crt, sc, cam, seed)
+    got = np.frombuffer(bytes(r.bvh_nodes()), np.uint32)
+    assert np.array_equal(got, np.frombuffer(bytes(onodes), np.uint32))
+    r.set_count_stats(True)
+    fb, st = r.render(crt.CRT_WORLD_BVH, spp, 0, 50)
+    sums, ost = orc.render(osc, ocam, seed, 0, spp, r.chunk_spp(spp), 50, onodes, nthreads=8)
+    assert _bits_equal(fb, sums * np.float32(1.0 / spp))
+    assert [st.rays, st.pair_visits, st.sphere_tests, st.samples] == ost
+    r.close()

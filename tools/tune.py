@@ -26,10 +26,10 @@ def make(variant, args):
         k, v = kv.split("=")
         os.environ[k] = v
     r = crt.Renderer(0, 1)
-    sc = crt.scene_random(18, args.half)
+    sc = crt.scene_random(18, args.half, args.ground)
     r.upload_scene(sc)
     r.build_bvh(17)
-    r.set_camera(crt.camera(args.width, args.spp, lookfrom=tuple(args.lookfrom)))
+    r.set_camera(crt.camera(args.width, args.spp, lookfrom=tuple(args.lookfrom), focus_dist=args.focus))
     if args.chunks:
         r.set_chunks(args.chunks)
     return r
@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--census", action="store_true")
     ap.add_argument("--lookfrom", type=float, nargs=3, default=[13, 2, 3])
+    ap.add_argument("--ground", type=float, default=1000.0)
+    ap.add_argument("--focus", type=float, default=10.0)
     args = ap.parse_args()
     rs = [make(v, args) for v in args.variants]
     buf = torch.zeros(args.width * args.width * 3, dtype=torch.float32, device="cuda:0")
