@@ -172,14 +172,8 @@ class Renderer:
         _check(lib().crt_set_camera(self._ctx, C.byref(cam)), "crt_set_camera", self._ctx)
         self.cam = cam
 
-    def set_chunks(self, chunks):
-        _check(lib().crt_set_chunks(self._ctx, chunks), "crt_set_chunks", self._ctx)
-
     def set_count_stats(self, enable):
         _check(lib().crt_set_count_stats(self._ctx, int(enable)), "crt_set_count_stats", self._ctx)
-
-    def chunk_spp(self, nsamples):
-        return lib().crt_chunk_spp(self._ctx, nsamples)
 
     def render(self, world, spp, sample_offset=0, max_depth=50):
         """crt_render: normalised framebuffer (H, W, 3) + stats."""
@@ -191,6 +185,10 @@ class Renderer:
     def render_accumulate(self, world, sample_offset, nsamples, max_depth, d_sums_ptr, stream=None):
         _check(lib().crt_render_accumulate(self._ctx, world, sample_offset, nsamples, max_depth, C.c_void_p(d_sums_ptr),
                                            C.c_void_p(stream or 0)), "crt_render_accumulate", self._ctx)
+
+    def resolve(self, d_sums_ptr, spp, d_fb_ptr, stream=None):
+        _check(lib().crt_resolve(self._ctx, C.c_void_p(d_sums_ptr), spp, C.c_void_p(d_fb_ptr), C.c_void_p(stream or 0)),
+               "crt_resolve", self._ctx)
 
     def stats(self):
         st = RenderStats()

@@ -15,7 +15,7 @@ EXPORTS = [
     "crt_camera_initialize", "crt_scene_small", "crt_scene_random", "crt_write_ppm", "crt_bvh_num_nodes",
     "crt_bvh_build_host", "crt_create", "crt_destroy", "crt_last_error", "crt_set_seed", "crt_upload_scene",
     "crt_build_bvh", "crt_get_bvh_nodes", "crt_set_camera", "crt_render", "crt_render_accumulate",
-    "crt_get_stats", "crt_get_kernel_times", "crt_chunk_spp", "crt_set_chunks", "crt_set_count_stats", "crt_trace_samples",
+    "crt_resolve", "crt_get_stats", "crt_get_kernel_times", "crt_set_count_stats", "crt_trace_samples",
 ]
 
 CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC = 0, 1, 2
@@ -83,9 +83,7 @@ def load(path=LIB_PATH):
     lib.crt_render_accumulate.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.crt_get_stats.argtypes = [vp, C.POINTER(RenderStats)]
     lib.crt_get_kernel_times.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
-    lib.crt_chunk_spp.restype = C.c_int32
-    lib.crt_chunk_spp.argtypes = [vp, C.c_int32]
-    lib.crt_set_chunks.argtypes = [vp, C.c_int32]
+    lib.crt_resolve.argtypes = [vp, vp, C.c_int32, vp, vp]
     lib.crt_set_count_stats.argtypes = [vp, C.c_int32]
     lib.crt_trace_samples.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, ip, C.c_int32, fp, fp, ip]
     lib.crt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]  # internal, not in the header

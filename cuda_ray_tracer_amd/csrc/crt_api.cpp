@@ -31,6 +31,7 @@ struct crt_context {
     void* d_spheres = nullptr;
     void* d_mats = nullptr;
     float* d_fb = nullptr;
+    unsigned long long* d_sums = nullptr;
     size_t fb_floats = 0;
     unsigned long long* d_counters = nullptr;
     int *d_px = nullptr, *d_py = nullptr, *d_smp = nullptr, *d_seg = nullptr;
@@ -43,7 +44,7 @@ struct crt_context {
     double wall_seconds = 0;
     // tuning
     int block = 512;
-    int chunks = 0;  // 0 = auto
+    int tiles_per_wg = 0;  // 0 = auto
     bool count_stats = false;
     bool census = false;
     size_t lds_limit = 64 * 1024;
@@ -65,14 +66,6 @@ int fail(crt_context* ctx, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                        \
             return fail(ctx, CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
-
-int pick_chunks(const crt_context* ctx, int nsamples) {
-    const int nw = ctx->block / 64;
-    if (ctx->chunks > 0) return ctx->chunks < nw ? ctx->chunks : nw;
-    int c = nw;
-    while (c > 1 && (nsamples + c - 1) / c < 8) c >>= 1;  // keep >= 8 samples per chunk
-    return c;
-}
 
 float as_float(int32_t bits) { float f; memcpy(&f, &bits, 4); return f; }
 
@@ -99,6 +92,7 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     ctx->device = device;
     ctx->seed = seed;
     if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 1024) ctx->block = v; }
+    if (const char* b = getenv("CRT_TILES")) { int v = atoi(b); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->tiles_per_wg = v; }
     if (const char* b = getenv("CRT_SCHED")) ctx->sched = atoi(b) != 0;
     if (const char* b = getenv("CRT_RUN_SHIFT")) { int v = atoi(b); if (v >= 0 && v <= 6) ctx->run_shift = v; }
     if (const char* b = getenv("CRT_LDS_LIMIT")) ctx->lds_limit = size_t(atol(b));
@@ -123,7 +117,7 @@ int crt_destroy(crt_context* ctx) {
     if (!ctx) return CRT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->d_pairs, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_counters, ctx->d_px, ctx->d_py,
+    void* bufs[] = {ctx->d_pairs, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_sums, ctx->d_counters, ctx->d_px, ctx->d_py,
                     ctx->d_smp, ctx->d_seg, ctx->d_ray7, ctx->d_rgb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (hipEvent_t e : ctx->ev_ring) if (e) (void)hipEventDestroy(e);
@@ -137,25 +131,11 @@ int crt_set_seed(crt_context* ctx, uint64_t seed) {
     return CRT_OK;
 }
 
-int crt_set_chunks(crt_context* ctx, int32_t chunks) {
-    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
-    if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16)
-        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_set_chunks: chunks must be 0, 1, 2, 4, 8 or 16");
-    ctx->chunks = chunks;
-    return CRT_OK;
-}
-
 int crt_set_count_stats(crt_context* ctx, int32_t enable) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     ctx->count_stats = enable != 0;
     ctx->census = enable == 2;  // internal: scheduler census for tools/tune.py
     return CRT_OK;
-}
-
-int32_t crt_chunk_spp(const crt_context* ctx, int32_t nsamples) {
-    if (!ctx || nsamples < 1) return 0;
-    const int c = pick_chunks(ctx, nsamples);
-    return (nsamples + c - 1) / c;
 }
 
 int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const float* motion, const float* radius,
@@ -258,7 +238,7 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam) {
     return CRT_OK;
 }
 
-static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth, float* d_sums, crt_render_args& a) {
+static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth, unsigned long long* d_sums, crt_render_args& a) {
     if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "render: no camera set");
     if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "render: no scene uploaded");
     if (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: unknown world kind");
@@ -274,8 +254,11 @@ static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth,
     a.num_leaves = ctx->num_leaves; a.n = ctx->n; a.m = ctx->m;
     a.key0 = uint32_t(ctx->seed); a.key1 = uint32_t(ctx->seed >> 32);
     a.s0 = s0; a.ns = ns;
-    a.chunks = pick_chunks(ctx, ns);
-    a.chunk_spp = (ns + a.chunks - 1) / a.chunks;
+    if (ns > (1 << 20)) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^20 samples in one call (split the range)");
+    // tiles per workgroup: enough (pixel, sample) items that every thread gets >= 16 of them
+    int t = ctx->tiles_per_wg;
+    if (t == 0) { t = 1; while (t < 16 && int64_t(64) * t * ns < int64_t(16) * ctx->block) t <<= 1; }
+    a.tiles_per_wg = t;
     a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
     a.max_depth = max_depth;
     a.sched = ctx->sched; a.census = ctx->census; a.run_shift = ctx->run_shift; a.leaf_num = ctx->leaf_num; a.shade_num = ctx->shade_num;
@@ -285,23 +268,23 @@ static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth,
 }
 
 int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
-                          int32_t max_depth, float* d_sums, void* stream_) {
+                          int32_t max_depth, int64_t* d_sums, void* stream_) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_accumulate: d_sums is NULL");
     crt_render_args a;
     memset(&a, 0, sizeof a);
-    if (int rc = fill_args(ctx, world, sample_offset, nsamples, max_depth, d_sums, a)) return rc;
+    if (int rc = fill_args(ctx, world, sample_offset, nsamples, max_depth, (unsigned long long*)d_sums, a)) return rc;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const int nw = ctx->block / 64;
-    const int tiles_per_block = nw / a.chunks;
     const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
-    const int grid = int((tiles + tiles_per_block - 1) / tiles_per_block);
-    size_t scene_bytes = 32 * size_t(ctx->n) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
+    const bool scheduled = world == CRT_WORLD_BVH && ctx->sched;
+    const int tiles_per_group = scheduled ? a.tiles_per_wg : nw;
+    const int grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
+    const size_t scene_bytes = 32 * size_t(ctx->n) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
     const bool in_lds = scene_bytes <= ctx->lds_limit;
     size_t lds = in_lds ? scene_bytes : 0;
-    const size_t red = a.chunks > 1 ? size_t(nw) * 3 * 64 * sizeof(float) : 0;
-    if (lds < red) lds = red;
+    if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
@@ -309,6 +292,15 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
     ctx->launches += 1;
     ctx->launched = true;
+    return CRT_OK;
+}
+
+int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!d_sums || !d_fb || spp < 1 || !ctx->have_cam) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_resolve: bad arguments or no camera");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t count = 3 * size_t(ctx->cam.image_width) * size_t(ctx->cam.image_height);
+    CRT_HIP_TRY(ctx, crt_launch_resolve(d_sums, d_fb, count, spp, (hipStream_t)stream));
     return CRT_OK;
 }
 
@@ -362,15 +354,17 @@ int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offs
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t floats = 3 * size_t(ctx->cam.image_width) * size_t(ctx->cam.image_height);
     if (ctx->fb_floats < floats) {
-        if (ctx->d_fb) { (void)hipFree(ctx->d_fb); ctx->d_fb = nullptr; ctx->fb_floats = 0; }
+        if (ctx->d_fb) { (void)hipFree(ctx->d_fb); ctx->d_fb = nullptr; }
+        if (ctx->d_sums) { (void)hipFree(ctx->d_sums); ctx->d_sums = nullptr; }
+        ctx->fb_floats = 0;
         CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_fb, floats * sizeof(float)));
+        CRT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sums, floats * sizeof(unsigned long long)));
         ctx->fb_floats = floats;
     }
-    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb, 0, floats * sizeof(float), nullptr));
-    if (int rc = crt_render_accumulate(ctx, world, sample_offset, spp, max_depth, ctx->d_fb, nullptr)) return rc;
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_sums, 0, floats * sizeof(unsigned long long), nullptr));
+    if (int rc = crt_render_accumulate(ctx, world, sample_offset, spp, max_depth, (int64_t*)ctx->d_sums, nullptr)) return rc;
+    if (int rc = crt_resolve(ctx, (const int64_t*)ctx->d_sums, spp, ctx->d_fb, nullptr)) return rc;  // camera.h:76 scale
     CRT_HIP_TRY(ctx, hipMemcpy(fb_host, ctx->d_fb, floats * sizeof(float), hipMemcpyDeviceToHost));
-    const float scale = float(1.0 / double(spp));  // camera.h:76 pixel_samples_scale
-    for (size_t i = 0; i < floats; ++i) fb_host[i] = fb_host[i] * scale;
     ctx->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) return crt_get_stats(ctx, stats);
     return CRT_OK;

@@ -17,7 +17,8 @@
 //  spheres : float4[2 * n]   { cx, cy, cz, radius }, { mx, my, mz, mat_id | type << 28 }
 //            (sphere.h:38-41: center ray origin, direction, radius, mat_ptr)
 //  mats    : float4[m]       lambertian/metal { r, g, b, fuzz }; dielectric { ior, 1/ior, -, - }
-//  sums    : float[3 * W * H] un-normalised RGB sums, row-major (helper.h:139-141 layout)
+//  sums    : int64[3 * W * H] un-normalised RGB sums in 2^-40 fixed point, row-major, RGB interleaved
+//            (the element order of helper.h:139-141's vec3 fb[W*H])
 #ifndef CRT_DEVICE_H
 #define CRT_DEVICE_H
 
@@ -44,15 +45,14 @@ struct crt_render_args {
     int m;           // materials
     uint32_t key0, key1;
     int s0, ns;      // first sample index, sample count of this call
-    int chunk_spp;   // samples per chunk
-    int chunks;      // chunks per workgroup (waves of one tile)
+    int tiles_per_wg;  // scheduled kernel: 8x8 tiles per workgroup (power of two)
     int tiles_x, tiles_y;
     int max_depth;
     int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
     int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
     int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
     int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
-    float* sums;
+    unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
     unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests
 };
 

@@ -1,10 +1,9 @@
 // crt_kernels.hip -- the hot path, hand-written for gfx950 (CDNA4, wave64).
 //
-// One lane owns one pixel of an 8x8 tile and walks that pixel's samples of one chunk in
-// order; when a path ends the lane regenerates its next sample inside the same loop
-// iteration, so a wave never idles on its longest path.  A workgroup is NW waves =
-// (tiles per block) x (chunks per tile); chunk sums meet in LDS and are added to the
-// framebuffer in chunk order -- no atomics, the result is deterministic.
+// A workgroup owns a few 8x8 pixel tiles and all samples of them; lanes pull (pixel, sample)
+// work items from a counter in LDS and are scheduled wave-wide by traversal phase (see
+// trace_bvh_scheduled).  Radiance is accumulated in 64-bit fixed point, so the image does not
+// depend on scheduling, launch geometry or GPU count -- it is deterministic by construction.
 //
 // The scene (child-pair BVH records and spheres; 48 KB for the reference's random-spheres
 // scene) is staged into LDS once per workgroup; scenes that do not fit
@@ -16,6 +15,8 @@
 // References: render_with_cuda.h:6-56,116-168; helper_experimental.h:1-78; sphere.h:44-73;
 // material.h:22-98; vec3.h:130-160; aabb.h:48-62.
 #include <hip/hip_runtime.h>
+
+#include <cmath>
 
 #include "crt_device.h"
 
@@ -328,35 +329,56 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Accumulation: a sample's radiance is added to its pixel as a 64-bit fixed-point number with 40
+// fractional bits (values >= 2^-16 are represented exactly, smaller ones are truncated to 2^-40).
+// Integer addition is associative, so the per-pixel sum does not depend on the order in which
+// samples finish, on the launch geometry, or on how samples are split over launches and GPUs.
+__device__ __forceinline__ unsigned long long to_fixed(float r) {
+    return (unsigned long long)(long long)(fminf(r, 4096.0f) * 1099511627776.0f);  // 2^40; NaN -> 4096
+}
+
 // Wave-scheduled BVH path tracer.  Every lane is a small state machine:
 //   RUN    walking internal nodes (one child-pair record per step),
 //   LEAF   holding one or two candidate spheres of a leaf-parent, waiting for the sphere phase,
 //   SHADE  traversal finished (or no path yet), waiting for hit record + scatter + next ray,
-//   DONE   all samples of the lane's chunk traced.
+//   DONE   the workgroup's item pool is empty.
 // Each iteration the WAVE picks one phase to run (wave-uniform branch on ballot counts): the
 // sphere and shade phases are postponed until enough lanes wait for them, so their code is not
 // re-executed for one or two lanes on every traversal step.  A lane's own sequence of operations
 // is exactly external_hit / ray_color (helper_experimental.h:1-78): a lane never steps past a
 // pending sphere test, so visit order, intervals and results are those of the simple loop.
+//
+// Work items.  A workgroup owns T tiles of 8x8 pixels and all `ns` samples of them: 64*T*ns items,
+// item i = sample (i / 64T), tile-pixel (i % 64T).  A lane that needs a path takes the next item
+// from a counter in LDS (one ds_add per wave and shade phase), so no lane idles while items are
+// left, whatever the path lengths of "its" pixels.  Radiance goes to fixed-point accumulators in
+// LDS (ds_add_u64) and from there to the frame with one global atomic per component.
 enum { ST_RUN = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
+
+struct wg_pool {
+    unsigned long long* acc;  // LDS: [64 * T][3]
+    uint32_t* counter;        // LDS: next unassigned item
+    const int2* origin;       // LDS: pixel origin (x, y) of each of the T tiles; x < 0: tile outside the frame
+    uint32_t total;           // 64 * T * ns
+    int shift;                // log2(64 * T)
+};
 
 template <bool IN_LDS, bool COUNT>
 __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const float4* pairs, const float4* spheres,
-                                                    const float4* mats, bool has_work, int px, int py,
-                                                    uint32_t pixel_index, int c0, int c1, v3& acc, uint32_t& n_rays,
+                                                    const float4* mats, const wg_pool& pool, uint32_t& n_rays,
                                                     uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests) {
     const float tmin = 0.001f;
     const uint32_t leaf_parents = (uint32_t)a.num_leaves >> 1;
-    stream rs; rs.k0 = a.key0; rs.k1 = a.key1; rs.pixel = pixel_index; rs.sample = 0; rs.event = 0;
+    const int lane = threadIdx.x & 63;
+    stream rs; rs.k0 = a.key0; rs.k1 = a.key1; rs.pixel = 0; rs.sample = 0; rs.event = 0;
     path_t p;
     p.r.o = mk(0, 0, 0); p.r.d = mk(0, 0, 1); p.r.tm = 0; p.thr = mk(1, 1, 1); p.sky_a = 0; p.depth = 0;
     v3 inv = mk(1, 1, 1);
     float ray_a = 1.0f, best_t = __builtin_huge_valf();
     int best_obj = -1, cand0 = -1, cand1 = -1;
-    uint32_t k = 1, pending = 0;
+    uint32_t k = 1, pending = 0, slot = 0;
     bool fresh = true, exact = false;
-    int s = c0;
-    int st = has_work ? ST_SHADE : ST_DONE;
+    int st = ST_SHADE;
 
     for (;;) {
         const unsigned long long m_run = __ballot(st == ST_RUN);
@@ -370,10 +392,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) phase = ST_SHADE;
         else if (n_run > 0) phase = ST_RUN;
         else phase = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
-        if (COUNT && a.census && (threadIdx.x & 63) == 0) {  // scheduler census: iterations and served lanes per phase
+        if (COUNT && a.census && lane == 0) {  // scheduler census: iterations and served lanes per phase
             const int served = phase == ST_RUN ? n_run : phase == ST_LEAF ? n_leaf : n_shade;
             atomicAdd(&a.counters[4 + 2 * phase], 1ull);
             atomicAdd(&a.counters[5 + 2 * phase], (unsigned long long)served);
+            atomicAdd(&a.counters[10], (unsigned long long)alive);
         }
 
         if (phase == ST_RUN) {
@@ -447,13 +470,40 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         rad = sky(p);
                         ended = true;
                     }
-                    if (ended) { acc = acc + rad; ++n_samples; ++s; fresh = true; }
+                    if (ended) {
+                        atomicAdd(&pool.acc[3 * slot + 0], to_fixed(rad.x));
+                        atomicAdd(&pool.acc[3 * slot + 1], to_fixed(rad.y));
+                        atomicAdd(&pool.acc[3 * slot + 2], to_fixed(rad.z));
+                        ++n_samples;
+                        fresh = true;
+                    }
                 }
-                if (fresh) {
-                    if (s >= c1) st = ST_DONE;
-                    else { start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s)); fresh = false; }
+                // lanes without a path take the next items of the workgroup's pool
+                const unsigned long long m_need = __ballot(fresh);
+                if (m_need != 0) {
+                    const int leader = __builtin_ctzll(m_need);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(pool.counter, (uint32_t)__popcll(m_need));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+                    if (fresh) {
+                        const uint32_t item = base + rank;
+                        if (item >= pool.total) {
+                            st = ST_DONE;
+                        } else {
+                            slot = item & ((1u << pool.shift) - 1u);
+                            const int2 org = pool.origin[slot >> 6];
+                            const int px = org.x + (int)(slot & 7u), py = org.y + (int)((slot >> 3) & 7u);
+                            if (org.x >= 0 && px < a.cam.width && py < a.cam.height) {
+                                start_path(p, rs, a, px, py, (uint32_t)(py * a.cam.width + px),
+                                           (uint32_t)a.s0 + (item >> pool.shift));
+                                fresh = false;
+                            }  // else: an item outside the frame; ask again in the next shade phase
+                        }
+                    }
                 }
-                if (st != ST_DONE) {  // begin external_hit for the new segment
+                if (st != ST_DONE && !fresh) {  // begin external_hit for the new segment
                     best_t = __builtin_huge_valf(); best_obj = -1;
                     ray_a = len2(p.r.d);
                     if (a.num_leaves == 1) {  // the root is the only leaf: no box is tested
@@ -477,63 +527,88 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     const float4* pairs = (const float4*)a.pairs;
     const float4* spheres = (const float4*)a.spheres;
     const float4* mats = (const float4*)a.mats;
+    const int np = (IN_LDS && WORLD == 1) ? 4 * a.num_leaves : 0, nsph = IN_LDS ? 2 * a.n : 0;
     if (IN_LDS) {
         // pairs + spheres in LDS (48 KB for the reference scene: three 512-thread workgroups per CU);
         // material records are read once per ray and stay in HBM/L2
-        const int np = (WORLD == 1) ? 4 * a.num_leaves : 0, ns = 2 * a.n;
         float4* s_pairs = smem;
         float4* s_spheres = smem + np;
         for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
-        for (int i = threadIdx.x; i < ns; i += BLOCK) s_spheres[i] = spheres[i];
-        __syncthreads();
+        for (int i = threadIdx.x; i < nsph; i += BLOCK) s_spheres[i] = spheres[i];
         pairs = s_pairs; spheres = s_spheres;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunks = a.chunks;  // power of two dividing NW
-    const int chunk = wave & (chunks - 1);
-    const int tile_local = wave / chunks;
-    const int tile = blockIdx.x * (NW / chunks) + tile_local;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-    const bool valid = (ty < a.tiles_y) && (px < a.cam.width) && (py < a.cam.height);
-    const uint32_t pixel_index = (uint32_t)(py * a.cam.width + px);
-    const int c0 = chunk * a.chunk_spp;
-    const int c1 = min(a.ns, c0 + a.chunk_spp);
-
-    v3 acc = mk(0.0f, 0.0f, 0.0f);
     uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
+
     if (WORLD == 1 && SCHED) {
-        trace_bvh_scheduled<IN_LDS, COUNT>(a, pairs, spheres, mats, valid && c0 < c1, px, py, pixel_index, c0, c1, acc,
-                                           n_rays, n_samples, n_pairs, n_tests);
-    } else if (valid && c0 < c1) {
-        stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
-        path_t p;
-        int s = c0;
-        start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
-        for (;;) {
-            hit_t h;
-            if (WORLD == 1) h = closest_hit_bvh<IN_LDS, COUNT>(pairs, spheres, a.num_leaves, p.r, n_pairs, n_tests);
-            else h = closest_hit_list<IN_LDS, COUNT>(spheres, a.n, p.r, n_tests);
-            ++n_rays;
-            bool ended;
-            v3 rad = mk(0.0f, 0.0f, 0.0f);
-            if (h.obj >= 0) {
-                const sphere_rec sp = load_sphere<IN_LDS>(spheres, h.obj);
-                const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
-                const bool cont = shade(p, rs, sp, mrec, h.t);
-                ++p.depth;
-                ended = !cont || (p.depth >= a.max_depth);  // absorbed or loop exhausted: black
-            } else {
-                rad = sky(p);
-                ended = true;
+        const int T = a.tiles_per_wg;  // power of two
+        unsigned long long* acc = (unsigned long long*)(smem + np + nsph);
+        int2* origin = (int2*)(acc + 192 * T);
+        uint32_t* counter = (uint32_t*)(origin + T);
+        for (int i = threadIdx.x; i < 192 * T; i += BLOCK) acc[i] = 0ull;
+        if (threadIdx.x < T) {
+            const int tile = blockIdx.x * T + threadIdx.x;
+            const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+            origin[threadIdx.x] = make_int2(ty < a.tiles_y ? tx * 8 : -1, ty * 8);
+        }
+        if (threadIdx.x == 0) *counter = 0u;
+        __syncthreads();
+        wg_pool pool;
+        pool.acc = acc; pool.counter = counter; pool.origin = origin;
+        pool.shift = 6 + (31 - __builtin_clz((unsigned)T));
+        pool.total = (uint32_t)a.ns << pool.shift;
+        trace_bvh_scheduled<IN_LDS, COUNT>(a, pairs, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 192 * T; i += BLOCK) {
+            const unsigned long long q = acc[i];
+            const int s = i / 3, c = i - 3 * s;
+            const int2 org = origin[s >> 6];
+            const int px = org.x + (s & 7), py = org.y + ((s >> 3) & 7);
+            if (q != 0ull && org.x >= 0 && px < a.cam.width && py < a.cam.height)
+                atomicAdd(&a.sums[3 * ((size_t)py * a.cam.width + px) + c], q);
+        }
+    } else {
+        // simple loop: a wave owns one tile, a lane one pixel and all its samples (brute-force list
+        // world, and the A/B reference of the scheduler)
+        if (IN_LDS) __syncthreads();
+        const int tile = blockIdx.x * NW + wave;
+        const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+        const bool valid = (ty < a.tiles_y) && (px < a.cam.width) && (py < a.cam.height);
+        const uint32_t pixel_index = (uint32_t)(py * a.cam.width + px);
+        if (valid) {
+            unsigned long long sx = 0, sy = 0, sz = 0;
+            stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
+            path_t p;
+            int s = 0;
+            start_path(p, rs, a, px, py, pixel_index, (uint32_t)a.s0);
+            for (;;) {
+                hit_t h;
+                if (WORLD == 1) h = closest_hit_bvh<IN_LDS, COUNT>(pairs, spheres, a.num_leaves, p.r, n_pairs, n_tests);
+                else h = closest_hit_list<IN_LDS, COUNT>(spheres, a.n, p.r, n_tests);
+                ++n_rays;
+                bool ended;
+                v3 rad = mk(0.0f, 0.0f, 0.0f);
+                if (h.obj >= 0) {
+                    const sphere_rec sp = load_sphere<IN_LDS>(spheres, h.obj);
+                    const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
+                    const bool cont = shade(p, rs, sp, mrec, h.t);
+                    ++p.depth;
+                    ended = !cont || (p.depth >= a.max_depth);  // absorbed or loop exhausted: black
+                } else {
+                    rad = sky(p);
+                    ended = true;
+                }
+                if (ended) {
+                    sx += to_fixed(rad.x); sy += to_fixed(rad.y); sz += to_fixed(rad.z);
+                    ++n_samples;
+                    ++s;
+                    if (s >= a.ns) break;
+                    start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
+                }
             }
-            if (ended) {
-                acc = acc + rad;
-                ++n_samples;
-                ++s;
-                if (s >= c1) break;
-                start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
-            }
+            unsigned long long* out = a.sums + 3 * (size_t)pixel_index;
+            atomicAdd(&out[0], sx); atomicAdd(&out[1], sy); atomicAdd(&out[2], sz);
         }
     }
 
@@ -542,36 +617,16 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         const uint32_t r = wave_sum(n_rays), sm = wave_sum(n_samples);
         if (lane == 0 && r) { atomicAdd(&a.counters[0], (unsigned long long)r); atomicAdd(&a.counters[1], (unsigned long long)sm); }
         if (COUNT) {
-            const uint32_t pv = wave_sum(n_pairs), st = wave_sum(n_tests);
-            if (lane == 0) { atomicAdd(&a.counters[2], (unsigned long long)pv); atomicAdd(&a.counters[3], (unsigned long long)st); }
+            const uint32_t pv = wave_sum(n_pairs), stt = wave_sum(n_tests);
+            if (lane == 0) { atomicAdd(&a.counters[2], (unsigned long long)pv); atomicAdd(&a.counters[3], (unsigned long long)stt); }
         }
     }
+}
 
-    // chunk sums -> framebuffer, in chunk order (LDS is reused: every wave is past its traversal)
-    float* red = (float*)smem;
-    if (chunks > 1) {
-        __syncthreads();
-        red[(wave * 3 + 0) * 64 + lane] = acc.x;
-        red[(wave * 3 + 1) * 64 + lane] = acc.y;
-        red[(wave * 3 + 2) * 64 + lane] = acc.z;
-        __syncthreads();
-    }
-    if (chunk == 0 && valid) {
-        float* out = a.sums + 3 * (size_t)pixel_index;
-        float r = out[0], g = out[1], b = out[2];
-        if (chunks > 1) {
-            const int used = (a.ns + a.chunk_spp - 1) / a.chunk_spp;  // non-empty chunks
-            for (int c = 0; c < used; ++c) {
-                const int w = tile_local * chunks + c;
-                r += red[(w * 3 + 0) * 64 + lane];
-                g += red[(w * 3 + 1) * 64 + lane];
-                b += red[(w * 3 + 2) * 64 + lane];
-            }
-        } else {
-            r += acc.x; g += acc.y; b += acc.z;
-        }
-        out[0] = r; out[1] = g; out[2] = b;
-    }
+// frame resolve: fixed-point sums -> fp32 radiance means, fb = float(double(sum) * (2^-40 / spp))
+__global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* sums, float* fb, size_t count, double scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) fb[i] = (float)((double)(long long)sums[i] * scale);
 }
 
 // single paths, for fine-grained parity checks (same device functions as the render kernel)
@@ -641,6 +696,13 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
 }
 
 }  // namespace
+
+hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream) {
+    const double scale = ldexp(1.0, -40) / (double)spp;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       (const unsigned long long*)sums, fb, count, scale);
+    return hipGetLastError();
+}
 
 // Host-visible launchers (called from crt_api.cpp)
 hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,

@@ -8,6 +8,7 @@
 
 hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
                              size_t lds_bytes, hipStream_t stream);
+hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream);
 hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
                                     const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream);
 

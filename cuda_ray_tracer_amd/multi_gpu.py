@@ -2,8 +2,10 @@
 
 The scene and BVH are replicated; rank g traces samples [g*spp/G, (g+1)*spp/G) of EVERY pixel --
 the Philox counter carries the global sample index, so the set of paths does not depend on G --
-into its own un-normalised fp32 sum buffer; one reduce(SUM) to rank 0 (RCCL over xGMI on GPUs,
-gloo in the CPU tests) combines them and rank 0 scales by 1/spp.  There is no other collective.
+into its own un-normalised sum buffer (int64, 2^-40 fixed point: crt_render_accumulate); one
+reduce(SUM) to rank 0 (RCCL over xGMI on GPUs, gloo in the CPU tests) combines them and rank 0
+resolves to fp32.  Integer sums are associative: the image is bit-identical for every G and every
+reduction order.  There is no other collective.
 """
 import torch
 import torch.distributed as dist
@@ -14,15 +16,19 @@ def sample_range(spp, world_size, rank):
     return rank * spp // world_size, (rank + 1) * spp // world_size
 
 
-def render_split(trace_range, sums, spp, world_size, rank, scale=True):
+def resolve(sums, spp):
+    """fp32 frame of fixed-point sums, the formula of crt_resolve: float(double(sum) * (2^-40 / spp))."""
+    return (sums.to(torch.float64) * (2.0 ** -40 / spp)).to(torch.float32)
+
+
+def render_split(trace_range, sums, spp, world_size, rank):
     """One image: zero `sums`, trace this rank's samples into it with `trace_range(lo, n, sums)`,
-    reduce to rank 0, normalise there.  `sums` is a (H, W, 3) fp32 tensor on the rank's device."""
+    reduce to rank 0.  `sums` is a (H, W, 3) int64 tensor on the rank's device; after the call rank
+    0 holds the sums of all `spp` samples (resolve them with crt_resolve / resolve())."""
     lo, hi = sample_range(spp, world_size, rank)
     sums.zero_()
     if hi > lo:
         trace_range(lo, hi - lo, sums)
     if world_size > 1:
         dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
-    if rank == 0 and scale:
-        sums.mul_(float(torch.tensor(1.0 / spp, dtype=torch.float64).to(torch.float32)))
     return sums

@@ -154,12 +154,19 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam);
 int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
                float* fb_host, crt_render_stats* stats);
 
-/* The same launch without the host round trip: ADDS the un-normalised per-pixel sums of
- * samples [sample_offset, sample_offset + nsamples) to the device buffer d_sums (W*H*3
- * floats) on `stream` (a hipStream_t; NULL = default stream).  Asynchronous.  This is
- * what multi-GPU sample splitting and progressive accumulation call. */
+/* The same launch without the host round trip: ADDS the un-normalised per-pixel sums of samples
+ * [sample_offset, sample_offset + nsamples) to the device buffer d_sums on `stream` (a
+ * hipStream_t; NULL = default stream).  Asynchronous.  d_sums is W*H*3 int64, row-major, RGB
+ * interleaved, in 2^-40 fixed point: each sample's radiance component r contributes
+ * (int64)(min(r, 4096) * 2^40).  Integer sums are associative, so the buffer -- and the image --
+ * is bit-identical however the samples are split over calls, workgroups or GPUs.  This is what
+ * multi-GPU sample splitting and progressive accumulation call. */
 int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
-                          int32_t max_depth, float* d_sums, void* stream);
+                          int32_t max_depth, int64_t* d_sums, void* stream);
+
+/* cam.pixel_samples_scale (camera.h:76, render_with_cuda.h:164): device buffer of fixed-point
+ * sums over `spp` samples -> fp32 frame, fb[i] = (float)((double)d_sums[i] * (2^-40 / spp)). */
+int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream);
 
 /* Waits for the last launch and returns its statistics. */
 int crt_get_stats(crt_context* ctx, crt_render_stats* stats);
@@ -169,14 +176,6 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats);
  * the last 64.  Waits for those launches. */
 int crt_get_kernel_times(crt_context* ctx, int32_t count, double* seconds_out);
 
-/* Summation contract: per pixel the samples of one call are summed in fp32 sequentially
- * in sample order inside chunks of crt_chunk_spp() consecutive samples, and the chunk
- * sums are added to the buffer in chunk order.  Returns that chunk size for a call of
- * `nsamples` samples (it depends on nsamples and on crt_set_chunks only). */
-int32_t crt_chunk_spp(const crt_context* ctx, int32_t nsamples);
-/* 0 = automatic; otherwise the number of sample chunks a workgroup splits a pixel tile
- * into (1, 2, 4, 8 or 16). */
-int crt_set_chunks(crt_context* ctx, int32_t chunks);
 /* enable (1) / disable (0) the pair_visits / sphere_tests counters (slower kernel variant) */
 int crt_set_count_stats(crt_context* ctx, int32_t enable);
 

@@ -685,19 +685,23 @@ int orc_bvh_build(int n, const float* center, const float* motion, const float* 
     return 2 * num_leaves - 1;
 }
 
-// Un-normalised per-pixel sums over samples [s0, s0+ns) for the pixel rectangle
-// [x0,x1)x[y0,y1): sequential fp32 sum in sample order inside each chunk of `chunk`
-// samples (chunk<=0: one chunk), chunk sums added in chunk order.  `sums` is W*H*3 and is
-// ADDED to (caller zeroes).  stats[0..3] += rays, pair visits, sphere tests, samples.
+// Accumulation contract of the product (include/crt_hip.h, crt_render_accumulate): a sample's
+// radiance component r contributes (int64)(min(r, 4096) * 2^40) to its pixel.  The reference adds
+// floats with atomicAdd in nondeterministic order (render_with_cuda.h:155-165); integer sums are
+// associative, so this sum is independent of any ordering.
+inline int64_t to_fixed(float r) { return (int64_t)(fminf(r, 4096.0f) * 1099511627776.0f); }
+
+// Un-normalised fixed-point per-pixel sums over samples [s0, s0+ns) for the pixel rectangle
+// [x0,x1)x[y0,y1).  `sums` is W*H*3 int64 and is ADDED to (caller zeroes).
+// stats[0..3] += rays, pair visits, sphere tests, samples.
 int orc_render(int n, const float* center, const float* motion, const float* radius, const int* mat_id,
                int m, const int* mtype, const float* malbedo, const float* mparam,
                const bvh_node* nodes, int num_nodes, const camera_derived* cam, uint64_t seed,
-               int x0, int y0, int x1, int y1, int s0, int ns, int chunk, int max_depth,
-               float* sums, uint64_t* stats, int nthreads) {
+               int x0, int y0, int x1, int y1, int s0, int ns, int max_depth,
+               int64_t* sums, uint64_t* stats, int nthreads) {
     scene world = make_scene(n, center, motion, radius, mat_id, m, mtype, malbedo, mparam);
     world.nodes = nodes; world.num_nodes = num_nodes;
     const int W = cam->image_width;
-    if (chunk <= 0) chunk = ns > 0 ? ns : 1;
     if (nthreads < 1) nthreads = 1;
     std::atomic<int> next_row(y0);
     std::vector<counters> cts(nthreads);
@@ -708,17 +712,13 @@ int orc_render(int n, const float* center, const float* motion, const float* rad
             if (j >= y1) break;
             for (int i = x0; i < x1; ++i) {
                 uint32_t pixel_index = (uint32_t)(j * W + i);
-                float* px = sums + 3 * (size_t)pixel_index;
-                for (int c0 = 0; c0 < ns; c0 += chunk) {
-                    color part(0, 0, 0);
-                    int c1 = std::min(ns, c0 + chunk);
-                    for (int s = c0; s < c1; ++s) {
-                        sample_stream rs(seed, pixel_index, (uint32_t)(s0 + s));
-                        ray r = get_ray(rs, *cam, i, j);
-                        part += ray_color(rs, r, world, max_depth, ct);
-                        ct.samples++;
-                    }
-                    px[0] += part.x(); px[1] += part.y(); px[2] += part.z();
+                int64_t* px = sums + 3 * (size_t)pixel_index;
+                for (int s = 0; s < ns; ++s) {
+                    sample_stream rs(seed, pixel_index, (uint32_t)(s0 + s));
+                    ray r = get_ray(rs, *cam, i, j);
+                    color c = ray_color(rs, r, world, max_depth, ct);
+                    px[0] += to_fixed(c.x()); px[1] += to_fixed(c.y()); px[2] += to_fixed(c.z());
+                    ct.samples++;
                 }
             }
         }
@@ -731,6 +731,12 @@ int orc_render(int n, const float* center, const float* motion, const float* rad
     }
     if (stats) for (auto& c : cts) { stats[0] += c.rays; stats[1] += c.pair_visits; stats[2] += c.sphere_tests; stats[3] += c.samples; }
     return 0;
+}
+
+// camera.h:76 + render_with_cuda.h:164 (pixel_samples_scale): fixed-point sums -> fp32 frame
+void orc_resolve(const int64_t* sums, size_t count, int spp, float* fb) {
+    const double scale = ldexp(1.0, -40) / (double)spp;
+    for (size_t i = 0; i < count; ++i) fb[i] = (float)((double)sums[i] * scale);
 }
 
 // One (pixel, sample): primary ray (7 floats: origin, direction, time), radiance (3), and

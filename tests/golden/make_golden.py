@@ -22,11 +22,11 @@ def main():
     for name, sc, depth in (("small", orc.scene_small(), 10), ("random", orc.scene_random(18, 11), 50)):
         nodes, order = orc.bvh_build(sc, 17)
         cam = orc.camera(W, SPP)
-        a, st_a = orc.render(sc, cam, SEED, 0, SPP, 0, depth, None)
-        b, st_b = orc.render(sc, cam, SEED, 0, SPP, 0, depth, nodes)
-        scale = np.float32(1.0 / SPP)
-        out[name + "_list"] = a * scale
-        out[name + "_bvh"] = b * scale
+        a, st_a = orc.render(sc, cam, SEED, 0, SPP, depth, None)
+        b, st_b = orc.render(sc, cam, SEED, 0, SPP, depth, nodes)
+        out[name + "_list"] = orc.resolve(a, SPP)
+        out[name + "_bvh"] = orc.resolve(b, SPP)
+        out[name + "_sums_bvh"] = b
         out[name + "_rays"] = np.int64(st_b[0])
         out[name + "_stats_bvh"] = np.array(st_b, np.int64)
         out[name + "_leaf_order"] = order

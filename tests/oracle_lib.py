@@ -62,8 +62,9 @@ def lib():
     L.orc_bvh_build.argtypes = [C.c_int, fp, fp, fp, C.c_uint32, C.POINTER(BvhNode), ip]
     scene_args = [C.c_int, fp, fp, fp, ip, C.c_int, ip, fp, fp]
     L.orc_render.argtypes = scene_args + [C.POINTER(BvhNode), C.c_int, C.POINTER(Camera), C.c_uint64,
-                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          fp, C.POINTER(C.c_uint64), C.c_int]
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_int]
+    L.orc_resolve.argtypes = [C.POINTER(C.c_int64), C.c_size_t, C.c_int, fp]
     L.orc_trace_sample.argtypes = scene_args + [C.POINTER(BvhNode), C.c_int, C.POINTER(Camera), C.c_uint64,
                                                 C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, ip]
     L.orc_closest_hit.argtypes = [C.c_int, fp, fp, fp, C.POINTER(BvhNode), C.c_int, fp, fp, fp, fp]
@@ -152,16 +153,24 @@ def nodes_to_array(nodes):
     return np.frombuffer(bytes(nodes), dtype=np.uint32).reshape(-1, 9).copy()
 
 
-def render(scene, cam, seed, s0, ns, chunk, max_depth, nodes=None, region=None, nthreads=1):
-    """Un-normalised sums (H, W, 3) + stats [rays, pair_visits, sphere_tests, samples]."""
+def render(scene, cam, seed, s0, ns, max_depth, nodes=None, region=None, nthreads=1):
+    """Fixed-point (2^-40) un-normalised sums, int64 (H, W, 3) + stats [rays, pair_visits, sphere_tests, samples]."""
     W, H = cam.image_width, cam.image_height
     x0, y0, x1, y1 = region if region else (0, 0, W, H)
-    sums = np.zeros((H, W, 3), np.float32)
+    sums = np.zeros((H, W, 3), np.int64)
     stats = (C.c_uint64 * 4)()
     nn = len(nodes) if nodes is not None else 0
-    lib().orc_render(*scene.args(), nodes, nn, C.byref(cam), seed, x0, y0, x1, y1, s0, ns, chunk, max_depth,
-                     _fp(sums), stats, nthreads)
+    lib().orc_render(*scene.args(), nodes, nn, C.byref(cam), seed, x0, y0, x1, y1, s0, ns, max_depth,
+                     sums.ctypes.data_as(C.POINTER(C.c_int64)), stats, nthreads)
     return sums, [int(v) for v in stats]
+
+
+def resolve(sums, spp):
+    """fp32 frame of fixed-point sums: float(double(sum) * (2^-40 / spp)) -- crt_resolve's formula."""
+    sums = np.ascontiguousarray(sums, np.int64)
+    fb = np.empty(sums.shape, np.float32)
+    lib().orc_resolve(sums.ctypes.data_as(C.POINTER(C.c_int64)), sums.size, spp, _fp(fb))
+    return fb
 
 
 def trace_sample(scene, cam, seed, px, py, sample, max_depth, nodes=None):

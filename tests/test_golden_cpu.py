@@ -15,14 +15,14 @@ def test_oracle_reproduces_golden(orc):
         assert np.array_equal(order, g[name + "_leaf_order"])
         assert np.array_equal(orc.nodes_to_array(nodes), g[name + "_nodes"])
         cam = orc.camera(64, 4)
-        a, _ = orc.render(sc, cam, seed, 0, 4, 0, depth, None)
-        b, st = orc.render(sc, cam, seed, 0, 4, 0, depth, nodes, nthreads=4)
-        scale = np.float32(0.25)
-        assert np.array_equal((a * scale).view(np.uint32), g[name + "_list"].view(np.uint32))
-        assert np.array_equal((b * scale).view(np.uint32), g[name + "_bvh"].view(np.uint32))
+        a, _ = orc.render(sc, cam, seed, 0, 4, depth, None)
+        b, st = orc.render(sc, cam, seed, 0, 4, depth, nodes, nthreads=4)
+        assert np.array_equal(orc.resolve(a, 4).view(np.uint32), g[name + "_list"].view(np.uint32))
+        assert np.array_equal(orc.resolve(b, 4).view(np.uint32), g[name + "_bvh"].view(np.uint32))
+        assert np.array_equal(b, g[name + "_sums_bvh"])
         assert st == g[name + "_stats_bvh"].tolist()
         # the BVH is only an acceleration structure: same image as the brute-force list
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(a, b)
     assert orc.scene_random(18, 11).n == int(g["random_n"])
 
 

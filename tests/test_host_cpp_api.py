@@ -34,7 +34,6 @@ def test_cli_builds_and_rejects_unknown_arguments(crt):
 def test_cli_ppm_matches_oracle(crt, orc):
     """rt_main --width 64 --samples 10 renders 32 spp (rounded up like main_experimental.cu:72);
     the PPM on stdout must equal the oracle's writer applied to the oracle's image."""
-    import numpy as np
     exe = os.path.join(PKG, "rt_main")
     assert os.path.exists(exe), "build it on the CPU box first (make -C cuda_ray_tracer_amd/csrc ../rt_main)"
     for scene, world in (("small", "bvh"), ("small", "list"), ("random", "bvh")):
@@ -46,9 +45,6 @@ def test_cli_ppm_matches_oracle(crt, orc):
         osc = orc.scene_small() if scene == "small" else orc.scene_random(18, 11)
         nodes = orc.bvh_build(osc, 17)[0] if world == "bvh" else None
         cam = orc.camera(64, 32)
-        rr = crt.Renderer(0, 5)
-        chunk = rr.chunk_spp(32)
-        rr.close()
-        sums, _ = orc.render(osc, cam, 5, 0, 32, chunk, 50, nodes, nthreads=8)
-        want = orc.write_ppm(sums * np.float32(1.0 / 32))
+        sums, _ = orc.render(osc, cam, 5, 0, 32, 50, nodes, nthreads=8)
+        want = orc.write_ppm(orc.resolve(sums, 32))
         assert r.stdout == want

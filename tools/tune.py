@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT")
 
 
 def make(variant, args):
@@ -30,8 +30,6 @@ def make(variant, args):
     r.upload_scene(sc)
     r.build_bvh(17)
     r.set_camera(crt.camera(args.width, args.spp, lookfrom=tuple(args.lookfrom), focus_dist=args.focus))
-    if args.chunks:
-        r.set_chunks(args.chunks)
     return r
 
 
@@ -42,14 +40,13 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--half", type=int, default=11)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--census", action="store_true")
     ap.add_argument("--lookfrom", type=float, nargs=3, default=[13, 2, 3])
     ap.add_argument("--ground", type=float, default=1000.0)
     ap.add_argument("--focus", type=float, default=10.0)
     args = ap.parse_args()
     rs = [make(v, args) for v in args.variants]
-    buf = torch.zeros(args.width * args.width * 3, dtype=torch.float32, device="cuda:0")
+    buf = torch.zeros(args.width * args.width * 3, dtype=torch.int64, device="cuda:0")
     times = [[] for _ in rs]
     rays = [0] * len(rs)
     ref = None
@@ -62,10 +59,10 @@ def main():
                 times[i].append(st.kernel_seconds * 1e3)
             rays[i] = st.rays
             if rnd == 0:
-                chk = float(buf.double().sum())
+                chk = int(buf.sum())
                 if ref is None:
                     ref = chk
-                print(f"# {args.variants[i]!r}: rays {st.rays} checksum {chk:.6f} {'OK' if chk == ref else 'DIFFERS'}", flush=True)
+                print(f"# {args.variants[i]!r}: rays {st.rays} checksum {chk} {'OK' if chk == ref else 'DIFFERS'}", flush=True)
     if args.census:
         import ctypes as C
         for i, r in enumerate(rs):
@@ -78,6 +75,7 @@ def main():
             c = list(c)
             names = ["RUN", "LEAF", "SHADE"]
             msg = " ".join(f"{names[j]}: iters {c[4 + 2 * j]} lanes/iter {c[5 + 2 * j] / max(1, c[4 + 2 * j]):.1f}" for j in range(3))
+            msg += f" alive/iter {c[10] / max(1, c[4] + c[6] + c[8]):.1f}"
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
     for i, v in enumerate(args.variants):
