@@ -48,7 +48,7 @@ struct crt_context {
     bool count_stats = false;
     bool census = false;
     size_t lds_limit = 64 * 1024;
-    int sched = 1, leaf_num = 4, shade_num = 6, run_shift = 1;
+    int sched = 1, leaf_num = 5, shade_num = 10, run_shift = 1;
 };
 
 namespace {
@@ -210,6 +210,13 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
         q[4] = l.ymin; q[5] = l.ymax; q[6] = r.ymin; q[7] = r.ymax;
         q[8] = l.zmin; q[9] = l.zmax; q[10] = r.zmin; q[11] = r.zmax;
         q[12] = as_float(tag_of(l)); q[13] = as_float(tag_of(r));
+        // An empty child (reference: interval(+inf,-inf), which a slab test does NOT reject)
+        // is stored as the degenerate far box [BIG,BIG]^3: (BIG - o) * inv gives near == far for a
+        // finite non-zero inv, hence max <= min and a miss without looking at the tag.  Rays with a
+        // non-finite reciprocal take the literal test, which does check the tag.
+        const float BIG = 3.0e38f;
+        if (tag_of(l) == CRT_TAG_EMPTY) { q[0] = q[1] = q[4] = q[5] = q[8] = q[9] = BIG; }
+        if (tag_of(r) == CRT_TAG_EMPTY) { q[2] = q[3] = q[6] = q[7] = q[10] = q[11] = BIG; }
     }
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, pairs.size() * sizeof(float)));
