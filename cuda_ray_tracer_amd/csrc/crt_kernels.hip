@@ -487,21 +487,47 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             }
         } else {
             if (st == ST_SHADE) {
+                // One Philox loop serves every lane of the phase, whatever it needs the block for:
+                //   K_VEC  an attempt of random_unit_vector (lambertian, metal)     vec3.h:145-152
+                //   K_U    the dielectric's reflect/refract draw                    material.h:78
+                //   K_CAM  the camera block of a new path, then K_DISK              render_with_cuda.h:11-26
+                // Each lane still draws ITS blocks in its own order (event counter per path); only
+                // the wave executes one Philox per iteration instead of one per material loop.
+                enum { K_NONE = 0, K_VEC = 1, K_U = 2, K_CAM = 3, K_DISK = 4 };
+                int kind = K_NONE, type = -1;
+                v3 nrm = mk(0, 0, 0), base = mk(0, 0, 0);
+                float scale = 0.0f, aux = 0.0f;          // VEC: fuzz / -, dielectric: cos_theta / ri
+                float u0 = 0, u1 = 0, u2 = 0, u3 = 0;    // VEC: p.xyz, lensq; K_U: u; CAM: x_off, y_off, time
+                bool cannot = false;
                 if (!fresh) {
                     ++n_rays;
-                    bool ended;
-                    v3 rad = mk(0.0f, 0.0f, 0.0f);
                     if (best_obj >= 0) {
+                        // hit record: sphere.h:66-70, hittable.h:16-22
                         const sphere_rec sp = load_sphere<IN_LDS>(spheres, best_obj);
                         const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
-                        const bool cont = shade(p, rs, sp, mrec, best_t);
-                        ++p.depth;
-                        ended = !cont || (p.depth >= a.max_depth);
+                        const v3 pos = p.r.o + best_t * p.r.d;
+                        const v3 cc = sp.c + p.r.tm * sp.mo;
+                        const v3 outward = (1.0f / sp.radius) * (pos - cc);
+                        const bool front = dot(p.r.d, outward) < 0.0f;
+                        nrm = front ? outward : -outward;
+                        type = (int)((uint32_t)sp.mat >> CRT_MAT_TYPE_SHIFT);
+                        p.r.o = pos;
+                        if (type == 0) {         // lambertian: nrm + ruv == nrm + 1.0f * ruv exactly
+                            base = nrm; scale = 1.0f; kind = K_VEC;
+                            p.thr = p.thr * mk(mrec.x, mrec.y, mrec.z);
+                        } else if (type == 1) {  // metal, material.h:50-51
+                            base = unit(p.r.d - (2.0f * dot(p.r.d, nrm)) * nrm); scale = mrec.w; kind = K_VEC;
+                            p.thr = p.thr * mk(mrec.x, mrec.y, mrec.z);
+                        } else {                 // dielectric, material.h:69-75
+                            aux = front ? mrec.y : mrec.x;
+                            base = unit(p.r.d);
+                            scale = fminf(dot(-base, nrm), 1.0f);
+                            const float sin_theta = sqrtf(1.0f - scale * scale);
+                            cannot = aux * sin_theta > 1.0f;
+                            kind = cannot ? K_NONE : K_U;  // the draw is short-circuited away under TIR
+                        }
                     } else {
-                        rad = sky(p);
-                        ended = true;
-                    }
-                    if (ended) {
+                        const v3 rad = sky(p);
                         atomicAdd(&pool.acc[3 * slot + 0], to_fixed(rad.x));
                         atomicAdd(&pool.acc[3 * slot + 1], to_fixed(rad.y));
                         atomicAdd(&pool.acc[3 * slot + 2], to_fixed(rad.z));
@@ -510,29 +536,93 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                 }
                 // lanes without a path take the next items of the workgroup's pool
+                int px = 0, py = 0;
                 const unsigned long long m_need = __ballot(fresh);
                 if (m_need != 0) {
                     const int leader = __builtin_ctzll(m_need);
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(pool.counter, (uint32_t)__popcll(m_need));
-                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    uint32_t first = 0;
+                    if (lane == leader) first = atomicAdd(pool.counter, (uint32_t)__popcll(m_need));
+                    first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
                     if (fresh) {
-                        const uint32_t item = base + rank;
+                        const uint32_t item = first + rank;
                         if (item >= pool.total) {
                             st = ST_DONE;
                         } else {
                             slot = item & ((1u << pool.shift) - 1u);
                             const int2 org = pool.origin[slot >> 6];
-                            const int px = org.x + (int)(slot & 7u), py = org.y + (int)((slot >> 3) & 7u);
+                            px = org.x + (int)(slot & 7u); py = org.y + (int)((slot >> 3) & 7u);
                             if (org.x >= 0 && px < a.cam.width && py < a.cam.height) {
-                                start_path(p, rs, a, px, py, (uint32_t)(py * a.cam.width + px),
-                                           (uint32_t)a.s0 + (item >> pool.shift));
+                                rs.pixel = (uint32_t)(py * a.cam.width + px);
+                                rs.sample = (uint32_t)a.s0 + (item >> pool.shift);
+                                rs.event = 0;
+                                kind = K_CAM;
                                 fresh = false;
                             }  // else: an item outside the frame; ask again in the next shade phase
                         }
                     }
+                }
+                // the shared block loop
+                float dx = 0.0f, dy = 0.0f;
+                while (kind != K_NONE) {
+                    const float4 b = rs.next_block();
+                    if (kind == K_VEC) {
+                        u0 = rf11(b.x); u1 = rf11(b.y); u2 = rf11(b.z);
+                        u3 = u0 * u0 + u1 * u1 + u2 * u2;
+                        if (0.0f < u3 && u3 <= 1.0f) kind = K_NONE;
+                    } else if (kind == K_U) {
+                        u0 = b.x; kind = K_NONE;
+                    } else if (kind == K_CAM) {
+                        u0 = b.x - 0.5f; u1 = b.y - 0.5f; u2 = 1.0f - b.z; kind = K_DISK;
+                    } else {  // K_DISK: two attempts per block
+                        dx = rf11(b.x); dy = rf11(b.y);
+                        if (dx * dx + dy * dy + 0.0f * 0.0f < 1.0f) kind = K_NONE;
+                        else {
+                            dx = rf11(b.z); dy = rf11(b.w);
+                            if (dx * dx + dy * dy + 0.0f * 0.0f < 1.0f) kind = K_NONE;
+                        }
+                    }
+                }
+                // finish: scatter direction, or the new primary ray
+                if (type >= 0) {
+                    v3 dir;
+                    bool absorbed = false;
+                    if (type <= 1) {
+                        const v3 ruv = (1.0f / sqrtf(u3)) * mk(u0, u1, u2);
+                        dir = base + scale * ruv;
+                        if (type == 0) {  // vec3.h:62-66 near_zero (double threshold)
+                            if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = nrm;
+                        } else {
+                            absorbed = !(dot(dir, nrm) > 0.0f);  // material.h:54
+                        }
+                    } else {
+                        bool do_reflect = cannot;
+                        if (!do_reflect) do_reflect = reflectance(scale, aux) > (1.0f - u0);
+                        if (do_reflect) {
+                            dir = base - (2.0f * dot(base, nrm)) * nrm;
+                        } else {  // refract, vec3.h:138-143
+                            const v3 perp = aux * (base + scale * nrm);
+                            const v3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * nrm;
+                            dir = perp + par;
+                        }
+                    }
+                    p.r.d = dir;
+                    ++p.depth;
+                    if (absorbed || p.depth >= a.max_depth) {  // black: nothing to add to the pixel
+                        ++n_samples;
+                        fresh = true;                          // takes its next item in the next shade phase
+                    }
+                } else if (!fresh && st != ST_DONE) {  // new path: render_with_cuda.h:14-28
+                    const v3 pixel_sample = (ld3(a.cam.p00) + (((float)px + u0) * ld3(a.cam.du))) +
+                                            (((float)py + u1) * ld3(a.cam.dv));
+                    const v3 p_in_disk = (ld3(a.cam.center) + dx * ld3(a.cam.ddu)) + dy * ld3(a.cam.ddv);
+                    p.r.o = (a.cam.defocus_angle <= 0.0f) ? ld3(a.cam.center) : p_in_disk;
+                    p.r.d = pixel_sample - p.r.o;
+                    p.r.tm = u2;
+                    p.thr = mk(1.0f, 1.0f, 1.0f);
+                    p.sky_a = 0.5f * (unit(p.r.d).y + 1.0f);
+                    p.depth = 0;
                 }
                 if (st != ST_DONE && !fresh) {  // begin external_hit for the new segment
                     best_t = __builtin_huge_valf(); best_obj = -1;
