@@ -43,11 +43,11 @@ struct crt_context {
     bool launched = false;
     double wall_seconds = 0;
     // tuning
-    int block = 512;
+    int block = 0;  // 0: chosen per launch from the LDS footprint (CRT_BLOCK overrides)
     int tiles_per_wg = 0;  // 0 = auto
     bool count_stats = false;
     bool census = false;
-    size_t lds_limit = 64 * 1024;
+    size_t lds_limit = 78 * 1024;  // two workgroups per CU
     int sched = 1, leaf_num = 5, shade_num = 10, run_shift = 1;
 };
 
@@ -91,7 +91,7 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     crt_context* ctx = new crt_context;
     ctx->device = device;
     ctx->seed = seed;
-    if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 1024) ctx->block = v; }
+    if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 768 || v == 1024) ctx->block = v; }
     if (const char* b = getenv("CRT_TILES")) { int v = atoi(b); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->tiles_per_wg = v; }
     if (const char* b = getenv("CRT_SCHED")) ctx->sched = atoi(b) != 0;
     if (const char* b = getenv("CRT_RUN_SHIFT")) { int v = atoi(b); if (v >= 0 && v <= 6) ctx->run_shift = v; }
@@ -200,8 +200,7 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
         return nd.loc_for_leaf >= 0 ? nd.loc_for_leaf : CRT_TAG_INTERNAL;
     };
     if (L == 1) {
-        pairs[12] = as_float(tag_of(ctx->nodes[0]));  // the root is the only leaf
-        pairs[13] = as_float(CRT_TAG_EMPTY);
+        pairs[12] = pairs[13] = as_float(tag_of(ctx->nodes[0]));  // the root is the only leaf (node 1 = "right" slot of record 0)
     }
     for (int k = 1; k < L; ++k) {
         const crt_bvh_node &l = ctx->nodes[2 * size_t(k) - 1], &r = ctx->nodes[2 * size_t(k)];
@@ -245,7 +244,7 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam) {
     return CRT_OK;
 }
 
-static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth, unsigned long long* d_sums, crt_render_args& a) {
+static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int max_depth, unsigned long long* d_sums, crt_render_args& a) {
     if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "render: no camera set");
     if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "render: no scene uploaded");
     if (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: unknown world kind");
@@ -264,7 +263,7 @@ static int fill_args(crt_context* ctx, int world, int s0, int ns, int max_depth,
     if (ns > (1 << 20)) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^20 samples in one call (split the range)");
     // tiles per workgroup: enough (pixel, sample) items that every thread gets >= 16 of them
     int t = ctx->tiles_per_wg;
-    if (t == 0) { t = 1; while (t < 16 && int64_t(64) * t * ns < int64_t(16) * ctx->block) t <<= 1; }
+    if (t == 0) { t = 1; while (t < 16 && int64_t(64) * t * ns < int64_t(16) * block) t <<= 1; }
     a.tiles_per_wg = t;
     a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
     a.max_depth = max_depth;
@@ -278,24 +277,32 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
                           int32_t max_depth, int64_t* d_sums, void* stream_) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_accumulate: d_sums is NULL");
+    // LDS image of the scene (render_kernel): spheres, and for a BVH world the pair records (simple
+    // loop, 64 B per pair) or the sign-sorted plane arrays + leaf tags (scheduled, 96 B + 4 B per pair)
+    const bool scheduled = world == CRT_WORLD_BVH && ctx->sched;
+    const size_t L = size_t(ctx->num_leaves);
+    size_t scene_bytes = 32 * size_t(ctx->n);
+    if (world == CRT_WORLD_BVH) scene_bytes += scheduled ? 96 * L + 16 * ((L - L / 2 + 1) / 2) : 64 * L;
+    const bool in_lds = scene_bytes <= ctx->lds_limit;
+    // workgroup size: 24 waves per CU (6 per SIMD at <= 80 VGPRs) from as many workgroups as the
+    // 160 KB of LDS hold
+    int block = ctx->block;
+    if (block == 0) block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
     crt_render_args a;
     memset(&a, 0, sizeof a);
-    if (int rc = fill_args(ctx, world, sample_offset, nsamples, max_depth, (unsigned long long*)d_sums, a)) return rc;
+    if (int rc = fill_args(ctx, world, block, sample_offset, nsamples, max_depth, (unsigned long long*)d_sums, a)) return rc;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
-    const int nw = ctx->block / 64;
+    const int nw = block / 64;
     const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
-    const bool scheduled = world == CRT_WORLD_BVH && ctx->sched;
     const int tiles_per_group = scheduled ? a.tiles_per_wg : nw;
     const int grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
-    const size_t scene_bytes = 32 * size_t(ctx->n) + (world == CRT_WORLD_BVH ? 64 * size_t(ctx->num_leaves) : 0);
-    const bool in_lds = scene_bytes <= ctx->lds_limit;
     size_t lds = in_lds ? scene_bytes : 0;
     if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
-    CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, ctx->block, grid, lds, stream));
+    CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
     ctx->launches += 1;
     ctx->launched = true;
@@ -384,7 +391,7 @@ int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int3
         return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: bad arguments");
     crt_render_args a;
     memset(&a, 0, sizeof a);
-    if (int rc = fill_args(ctx, world, 0, 1, max_depth, nullptr, a)) return rc;
+    if (int rc = fill_args(ctx, world, 512, 0, 1, max_depth, nullptr, a)) return rc;
     for (int i = 0; i < count; ++i)
         if (px[i] < 0 || px[i] >= ctx->cam.image_width || py[i] < 0 || py[i] >= ctx->cam.image_height || sample[i] < 0)
             return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: pixel or sample out of range");

@@ -386,20 +386,38 @@ struct wg_pool {
     int shift;                // log2(64 * T)
 };
 
+// Scene access of the walking loop.  In LDS (IN_LDS) the child boxes are stored once per ray
+// direction sign: array 2*axis + (dir[axis] < 0) holds, for pair k, (near_L, far_L, near_R, far_R) =
+// the box planes this ray meets first / last on that axis.  A lane reads three float4 (one per axis,
+// picked by ITS signs), and max/min over known near/far planes replace the per-axis min/max pair:
+// t_near/t_far are the same products (b - o) * inv the reference forms, only looked up instead of
+// compared (plane_lo <= plane_hi and rounding is monotone, so near == min and far == max exactly).
+struct walk_scene {
+    const float4* pairs;      // HBM: 64-byte child-pair records (crt_device.h), always valid
+    const float4* axes;       // LDS: [6][L] sign-sorted planes, or null
+    const int2* leaf_tags;    // LDS: sphere tags of the leaf-parents' children, indexed by pair index (pre-offset)
+    uint32_t L;               // num_leaves
+};
+
 template <bool IN_LDS, bool COUNT>
-__device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const float4* pairs, const float4* spheres,
+__device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const walk_scene& ws, const float4* spheres,
                                                     const float4* mats, const wg_pool& pool, uint32_t& n_rays,
                                                     uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests) {
     const float tmin = 0.001f;
-    const uint32_t leaf_parents = (uint32_t)a.num_leaves >> 1;
+    const float4* pairs = ws.pairs;
+    const uint32_t NL = ws.L;
     const int lane = threadIdx.x & 63;
     stream rs; rs.k0 = a.key0; rs.k1 = a.key1; rs.pixel = 0; rs.sample = 0; rs.event = 0;
     path_t p;
     p.r.o = mk(0, 0, 0); p.r.d = mk(0, 0, 1); p.r.tm = 0; p.thr = mk(1, 1, 1); p.sky_a = 0; p.depth = 0;
     v3 inv = mk(1, 1, 1);
     float ray_a = 1.0f, best_t = __builtin_huge_valf();
-    int best_obj = -1, cand0 = -1, cand1 = -1;
+    int best_obj = -1;
+    // k: RUN = the pair (1-based heap index of the parent) to test next; LEAF = the first hit leaf
+    // node, its sibling k^1 also hit when bit 0 of `pending` is set.  pending: bit i = the right
+    // sibling i levels above the current level is still to be visited.
     uint32_t k = 1, pending = 0, slot = 0;
+    uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: float4 index of this ray's plane arrays
     bool fresh = true, exact = false;
     int st = ST_SHADE;
 
@@ -427,38 +445,44 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             const int leave_at = n_run - max(1, n_run >> a.run_shift);
             for (;;) {
                 if (st == ST_RUN) {
-                    const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
-                    const int tagL = __float_as_int(q3.x), tagR = __float_as_int(q3.y);
                     if (COUNT) n_pairs += 1;
                     bool hitL, hitR;
                     if (__builtin_expect(exact, 0)) {
+                        // a zero/denormal direction component: the literal comparisons of aabb.h:48-62
+                        const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
                         hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
                         hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
-                        hitL = hitL & (tagL != CRT_TAG_EMPTY);
-                        hitR = hitR & (tagR != CRT_TAG_EMPTY);
+                        hitL = hitL & (__float_as_int(q3.x) != CRT_TAG_EMPTY);
+                        hitR = hitR & (__float_as_int(q3.y) != CRT_TAG_EMPTY);
+                    } else if (IN_LDS) {
+                        // empty children carry a far-away degenerate box (crt_api.cpp): near == far on
+                        // every axis, so max(near) >= min(far) and the test rejects them by itself
+                        const float4 ax = ws.axes[offx + k], ay = ws.axes[offy + k], az = ws.axes[offz + k];
+                        const float nLx = (ax.x - p.r.o.x) * inv.x, fLx = (ax.y - p.r.o.x) * inv.x;
+                        const float nRx = (ax.z - p.r.o.x) * inv.x, fRx = (ax.w - p.r.o.x) * inv.x;
+                        const float nLy = (ay.x - p.r.o.y) * inv.y, fLy = (ay.y - p.r.o.y) * inv.y;
+                        const float nRy = (ay.z - p.r.o.y) * inv.y, fRy = (ay.w - p.r.o.y) * inv.y;
+                        const float nLz = (az.x - p.r.o.z) * inv.z, fLz = (az.y - p.r.o.z) * inv.z;
+                        const float nRz = (az.z - p.r.o.z) * inv.z, fRz = (az.w - p.r.o.z) * inv.z;
+                        const float loL = fmaxf(fmaxf(fmaxf(nLx, nLy), nLz), tmin), hiL = fminf(fminf(fminf(fLx, fLy), fLz), best_t);
+                        const float loR = fmaxf(fmaxf(fmaxf(nRx, nRy), nRz), tmin), hiR = fminf(fminf(fminf(fRx, fRy), fRz), best_t);
+                        hitL = !(hiL <= loL);
+                        hitR = !(hiR <= loR);
                     } else {
-                        // empty children carry a far-away degenerate box (crt_api.cpp) that this
-                        // test rejects by itself whenever the reciprocals are finite: no tag compare
-                        if (CRT_PACKED_SLAB) {
-                            slab_pair_fast(q0, q1, q2, p.r.o, inv, tmin, best_t, hitL, hitR);
-                        } else {
-                            hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
-                            hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
-                        }
+                        const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2];
+                        hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
+                        hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
                     }
-                    // branch-free successor: descend (left first, right remembered), hold the leaf
-                    // candidates (left sphere first, then right), or pop the pending right sibling
+                    // branch-free successor: descend (left first, right remembered) -- onto a leaf:
+                    // hold it for the sphere phase -- or pop the nearest pending right sibling
                     const bool both = hitL & hitR, any = hitL | hitR;
-                    const bool leafp = k >= leaf_parents;
-                    cand0 = hitL ? tagL : tagR;
-                    cand1 = both ? tagR : -1;
+                    const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
                     const uint32_t up = (uint32_t)__builtin_ctz(pending | 0x80000000u);
-                    const uint32_t k_pop = (k >> up) ^ 1u, p_pop = (pending >> up) ^ 1u;
-                    const uint32_t k_down = 2u * k + (hitL ? 0u : 1u), p_down = (pending << 1) | (both ? 1u : 0u);
+                    const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
                     const bool done = !any & (pending == 0);
-                    const bool hold = any & leafp;
-                    k = any ? (leafp ? k : k_down) : k_pop;
-                    pending = any ? (leafp ? pending : p_down) : p_pop;
+                    const bool hold = any & (kd >= NL);
+                    k = any ? kd : kp;
+                    pending = any ? pd : pp;
                     st = hold ? ST_LEAF : (done ? ST_SHADE : ST_RUN);
                 }
                 const int still = __popcll(__ballot(st == ST_RUN));
@@ -467,6 +491,12 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             }
         } else if (phase == ST_LEAF) {
             if (st == ST_LEAF) {
+                // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
+                int2 tg;
+                if (IN_LDS) tg = ws.leaf_tags[k >> 1];
+                else { const float4 q3 = pairs[4 * (k >> 1) + 3]; tg = make_int2(__float_as_int(q3.x), __float_as_int(q3.y)); }
+                const int cand0 = (k & 1u) ? tg.y : tg.x;
+                const int cand1 = (pending & 1u) ? tg.y : -1;
                 {
                     const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand0), p.r, ray_a, tmin, best_t);
                     if (COUNT) n_tests += 1;
@@ -477,6 +507,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (COUNT) n_tests += 1;
                     if (root > 0.0f) { best_t = root; best_obj = cand1; }
                 }
+                pending &= ~1u;
                 if (pending == 0) { st = ST_SHADE; }
                 else {
                     const int up = __builtin_ctz(pending);
@@ -566,6 +597,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 // the shared block loop
                 float dx = 0.0f, dy = 0.0f;
                 while (kind != K_NONE) {
+                    if (COUNT && a.census) {  // block-loop census: iterations (per wave) and lanes served
+                        const unsigned long long m_blk = __ballot(true);
+                        if (lane == __builtin_ctzll(m_blk)) { atomicAdd(&a.counters[13], 1ull); atomicAdd(&a.counters[14], (unsigned long long)__popcll(m_blk)); }
+                    }
                     const float4 b = rs.next_block();
                     if (kind == K_VEC) {
                         u0 = rf11(b.x); u1 = rf11(b.y); u2 = rf11(b.z);
@@ -627,11 +662,16 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 if (st != ST_DONE && !fresh) {  // begin external_hit for the new segment
                     best_t = __builtin_huge_valf(); best_obj = -1;
                     ray_a = len2(p.r.d);
-                    if (a.num_leaves == 1) {  // the root is the only leaf: no box is tested
-                        cand0 = __float_as_int(pairs[3].x); cand1 = -1; pending = 0; st = ST_LEAF;
+                    if (NL == 1) {  // the root is the only leaf: no box is tested
+                        k = 1; pending = 0; st = ST_LEAF;
                     } else {
                         inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
                         exact = !finite3(inv);
+                        if (IN_LDS) {
+                            offx = p.r.d.x < 0.0f ? NL : 0u;
+                            offy = p.r.d.y < 0.0f ? 3u * NL : 2u * NL;
+                            offz = p.r.d.z < 0.0f ? 5u * NL : 4u * NL;
+                        }
                         k = 1; pending = 0; st = ST_RUN;
                     }
                 }
@@ -648,15 +688,35 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     const float4* pairs = (const float4*)a.pairs;
     const float4* spheres = (const float4*)a.spheres;
     const float4* mats = (const float4*)a.mats;
-    const int np = (IN_LDS && WORLD == 1) ? 4 * a.num_leaves : 0, nsph = IN_LDS ? 2 * a.n : 0;
+    // LDS image of the scene, in float4 units: the scheduled kernel keeps the sign-sorted plane
+    // arrays (6 * L) and the leaf pairs' sphere tags, the simple loop the pair records (4 * L)
+    const int L = a.num_leaves;
+    const int leaf_parents = L >> 1, n_tagrec = L - leaf_parents;  // pairs [leaf_parents, L) hold sphere tags
+    const int np = !(IN_LDS && WORLD == 1) ? 0 : (SCHED ? 6 * L + (n_tagrec + 1) / 2 : 4 * L);
+    const int nsph = IN_LDS ? 2 * a.n : 0;
+    walk_scene ws;
+    ws.pairs = pairs; ws.axes = nullptr; ws.leaf_tags = nullptr; ws.L = (uint32_t)L;
     if (IN_LDS) {
-        // pairs + spheres in LDS (48 KB for the reference scene: three 512-thread workgroups per CU);
         // material records are read once per ray and stay in HBM/L2
         float4* s_pairs = smem;
         float4* s_spheres = smem + np;
-        for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
+        if (WORLD == 1 && SCHED) {
+            int2* s_tags = (int2*)(smem + 6 * L);
+            for (int k = threadIdx.x; k < L; k += BLOCK) {
+                const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+                s_pairs[k] = q0;         s_pairs[L + k] = make_float4(q0.y, q0.x, q0.w, q0.z);
+                s_pairs[2 * L + k] = q1; s_pairs[3 * L + k] = make_float4(q1.y, q1.x, q1.w, q1.z);
+                s_pairs[4 * L + k] = q2; s_pairs[5 * L + k] = make_float4(q2.y, q2.x, q2.w, q2.z);
+                if (k >= leaf_parents) s_tags[k - leaf_parents] = make_int2(__float_as_int(q3.x), __float_as_int(q3.y));
+            }
+            ws.axes = s_pairs;
+            ws.leaf_tags = s_tags - leaf_parents;
+        } else {
+            for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
+            pairs = s_pairs;
+        }
         for (int i = threadIdx.x; i < nsph; i += BLOCK) s_spheres[i] = spheres[i];
-        pairs = s_pairs; spheres = s_spheres;
+        spheres = s_spheres;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
@@ -678,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         pool.acc = acc; pool.counter = counter; pool.origin = origin;
         pool.shift = 6 + (31 - __builtin_clz((unsigned)T));
         pool.total = (uint32_t)a.ns << pool.shift;
-        trace_bvh_scheduled<IN_LDS, COUNT>(a, pairs, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
+        trace_bvh_scheduled<IN_LDS, COUNT>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
         __syncthreads();
         for (int i = threadIdx.x; i < 192 * T; i += BLOCK) {
             const unsigned long long q = acc[i];
@@ -811,6 +871,7 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
     switch (block) {
         case 256: return launch_one<WORLD, IN_LDS, COUNT, 256>(a, grid, lds_bytes, stream);
         case 512: return launch_one<WORLD, IN_LDS, COUNT, 512>(a, grid, lds_bytes, stream);
+        case 768: return launch_one<WORLD, IN_LDS, COUNT, 768>(a, grid, lds_bytes, stream);
         case 1024: return launch_one<WORLD, IN_LDS, COUNT, 1024>(a, grid, lds_bytes, stream);
     }
     return hipErrorInvalidValue;
