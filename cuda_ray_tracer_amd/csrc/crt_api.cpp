@@ -48,7 +48,7 @@ struct crt_context {
     bool count_stats = false;
     bool census = false;
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
-    int sched = 1, leaf_num = 5, shade_num = 10, run_shift = 1;
+    int sched = 1, leaf_num = 4, shade_num = 11, run_shift = 1;
 };
 
 namespace {
@@ -190,6 +190,7 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
     if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "crt_build_bvh: no scene uploaded");
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    if (crt::bvh_depth(ctx->n) > 28) return fail(ctx, CRT_ERR_TOO_LARGE, "crt_build_bvh: tree deeper than 28 levels (the traversal keeps one bit per level in 32)");
     const int L = 1 << crt::bvh_depth(ctx->n);
     ctx->nodes.resize(2 * size_t(L) - 1);
     crt::bvh_build(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), axis_seed, ctx->nodes.data());

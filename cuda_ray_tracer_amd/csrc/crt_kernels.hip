@@ -413,18 +413,21 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     v3 inv = mk(1, 1, 1);
     float ray_a = 1.0f, best_t = __builtin_huge_valf();
     int best_obj = -1;
-    // k: RUN = the pair (1-based heap index of the parent) to test next; LEAF = the first hit leaf
-    // node, its sibling k^1 also hit when bit 0 of `pending` is set.  pending: bit i = the right
-    // sibling i levels above the current level is still to be visited.
-    uint32_t k = 1, pending = 0, slot = 0;
-    uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: float4 index of this ray's plane arrays
-    bool fresh = true, exact = false;
-    int st = ST_SHADE;
+    // The traversal state IS the node index k (1-based heap order, NL = number of leaves):
+    //   0 < k < NL   RUN: k is the pair (parent) whose two child boxes are tested next
+    //   k >= NL      LEAF: k is the first hit leaf, its sibling k^1 was hit too if bit 0 of `pending` is set
+    //   k == 0       SHADE (traversal finished or no path yet), or DONE once `finished`
+    // pending: bit i = the right sibling i levels above the current level is still to be visited;
+    // above the root's level sits a sentinel bit, so a pop is always defined and popping the
+    // sentinel yields k == 0.
+    uint32_t k = 0, pending = 0, slot = 0;
+    uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: byte offset of this ray's plane arrays (+ base)
+    bool fresh = true, exact = false, finished = false;
 
     for (;;) {
-        const unsigned long long m_run = __ballot(st == ST_RUN);
-        const unsigned long long m_leaf = __ballot(st == ST_LEAF);
-        const unsigned long long m_shade = __ballot(st == ST_SHADE);
+        const unsigned long long m_run = __ballot((k - 1u) < (NL - 1u));
+        const unsigned long long m_leaf = __ballot(k >= NL);
+        const unsigned long long m_shade = __ballot((k == 0u) & !finished);
         const int n_run = __popcll(m_run), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade);
         const int alive = n_run + n_leaf + n_shade;
         if (alive == 0) break;
@@ -443,8 +446,9 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         if (phase == ST_RUN) {
             // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
             const int leave_at = n_run - max(1, n_run >> a.run_shift);
+            bool walking = (k - 1u) < (NL - 1u);
             for (;;) {
-                if (st == ST_RUN) {
+                if (walking) {
                     if (COUNT) n_pairs += 1;
                     bool hitL, hitR;
                     if (__builtin_expect(exact, 0)) {
@@ -457,7 +461,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     } else if (IN_LDS) {
                         // empty children carry a far-away degenerate box (crt_api.cpp): near == far on
                         // every axis, so max(near) >= min(far) and the test rejects them by itself
-                        const float4 ax = ws.axes[offx + k], ay = ws.axes[offy + k], az = ws.axes[offz + k];
+                        const char* planes = (const char*)ws.axes;
+                        const float4 ax = *(const float4*)(planes + ((k << 4) + offx));
+                        const float4 ay = *(const float4*)(planes + ((k << 4) + offy));
+                        const float4 az = *(const float4*)(planes + ((k << 4) + offz));
                         const float nLx = (ax.x - p.r.o.x) * inv.x, fLx = (ax.y - p.r.o.x) * inv.x;
                         const float nRx = (ax.z - p.r.o.x) * inv.x, fRx = (ax.w - p.r.o.x) * inv.x;
                         const float nLy = (ay.x - p.r.o.y) * inv.y, fLy = (ay.y - p.r.o.y) * inv.y;
@@ -477,20 +484,18 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     // hold it for the sphere phase -- or pop the nearest pending right sibling
                     const bool both = hitL & hitR, any = hitL | hitR;
                     const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
-                    const uint32_t up = (uint32_t)__builtin_ctz(pending | 0x80000000u);
+                    const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
                     const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
-                    const bool done = !any & (pending == 0);
-                    const bool hold = any & (kd >= NL);
                     k = any ? kd : kp;
                     pending = any ? pd : pp;
-                    st = hold ? ST_LEAF : (done ? ST_SHADE : ST_RUN);
                 }
-                const int still = __popcll(__ballot(st == ST_RUN));
+                walking = (k - 1u) < (NL - 1u);
+                const int still = __popcll(__ballot(walking));
                 if (COUNT && a.census && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)still); }
                 if (still <= leave_at) break;
             }
         } else if (phase == ST_LEAF) {
-            if (st == ST_LEAF) {
+            if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
                 int2 tg;
                 if (IN_LDS) tg = ws.leaf_tags[k >> 1];
@@ -508,16 +513,15 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (root > 0.0f) { best_t = root; best_obj = cand1; }
                 }
                 pending &= ~1u;
-                if (pending == 0) { st = ST_SHADE; }
+                if (NL == 1u) { k = 0u; }  // the root was the only leaf
                 else {
                     const int up = __builtin_ctz(pending);
                     k = (k >> up) ^ 1u;
                     pending = (pending >> up) ^ 1u;
-                    st = ST_RUN;
                 }
             }
         } else {
-            if (st == ST_SHADE) {
+            if ((k == 0u) & !finished) {
                 // One Philox loop serves every lane of the phase, whatever it needs the block for:
                 //   K_VEC  an attempt of random_unit_vector (lambertian, metal)     vec3.h:145-152
                 //   K_U    the dielectric's reflect/refract draw                    material.h:78
@@ -579,7 +583,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (fresh) {
                         const uint32_t item = first + rank;
                         if (item >= pool.total) {
-                            st = ST_DONE;
+                            finished = true;
                         } else {
                             slot = item & ((1u << pool.shift) - 1u);
                             const int2 org = pool.origin[slot >> 6];
@@ -648,7 +652,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         ++n_samples;
                         fresh = true;                          // takes its next item in the next shade phase
                     }
-                } else if (!fresh && st != ST_DONE) {  // new path: render_with_cuda.h:14-28
+                } else if (!fresh && !finished) {  // new path: render_with_cuda.h:14-28
                     const v3 pixel_sample = (ld3(a.cam.p00) + (((float)px + u0) * ld3(a.cam.du))) +
                                             (((float)py + u1) * ld3(a.cam.dv));
                     const v3 p_in_disk = (ld3(a.cam.center) + dx * ld3(a.cam.ddu)) + dy * ld3(a.cam.ddv);
@@ -659,20 +663,20 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     p.sky_a = 0.5f * (unit(p.r.d).y + 1.0f);
                     p.depth = 0;
                 }
-                if (st != ST_DONE && !fresh) {  // begin external_hit for the new segment
+                if (!finished && !fresh) {  // begin external_hit for the new segment
                     best_t = __builtin_huge_valf(); best_obj = -1;
                     ray_a = len2(p.r.d);
-                    if (NL == 1) {  // the root is the only leaf: no box is tested
-                        k = 1; pending = 0; st = ST_LEAF;
+                    k = 1u; pending = 1u;  // the root, below the sentinel
+                    if (NL == 1u) {
+                        // the root is the only leaf (k >= NL: sphere phase next): no box is tested
                     } else {
                         inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
                         exact = !finite3(inv);
                         if (IN_LDS) {
-                            offx = p.r.d.x < 0.0f ? NL : 0u;
-                            offy = p.r.d.y < 0.0f ? 3u * NL : 2u * NL;
-                            offz = p.r.d.z < 0.0f ? 5u * NL : 4u * NL;
+                            offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
+                            offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
+                            offz = (p.r.d.z < 0.0f ? 5u * NL : 4u * NL) << 4;
                         }
-                        k = 1; pending = 0; st = ST_RUN;
                     }
                 }
             }
