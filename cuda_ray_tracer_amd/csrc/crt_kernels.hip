@@ -425,25 +425,30 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     bool fresh = true, exact = false, finished = false;
 
     for (;;) {
+      // The scheduler, the walking phase and the sphere phase form an inner loop of their own: it
+      // changes only k, `pending` and the best hit, so the rest of the lane state stays in place in
+      // its registers across it (no copies at the loop's merge points).
+      int phase = -1;
+      for (;;) {
         const unsigned long long m_run = __ballot((k - 1u) < (NL - 1u));
         const unsigned long long m_leaf = __ballot(k >= NL);
         const unsigned long long m_shade = __ballot((k == 0u) & !finished);
         const int n_run = __popcll(m_run), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade);
         const int alive = n_run + n_leaf + n_shade;
         if (alive == 0) break;
-        int phase;
-        if (n_leaf * 16 >= alive * a.leaf_num && n_leaf > 0) phase = ST_LEAF;
-        else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) phase = ST_SHADE;
-        else if (n_run > 0) phase = ST_RUN;
-        else phase = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
+        int ph;
+        if (n_leaf * 16 >= alive * a.leaf_num && n_leaf > 0) ph = ST_LEAF;
+        else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) ph = ST_SHADE;
+        else if (n_run > 0) ph = ST_RUN;
+        else ph = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
         if (COUNT && a.census && lane == 0) {  // scheduler census: iterations and served lanes per phase
-            const int served = phase == ST_RUN ? n_run : phase == ST_LEAF ? n_leaf : n_shade;
-            atomicAdd(&a.counters[4 + 2 * phase], 1ull);
-            atomicAdd(&a.counters[5 + 2 * phase], (unsigned long long)served);
+            const int served = ph == ST_RUN ? n_run : ph == ST_LEAF ? n_leaf : n_shade;
+            atomicAdd(&a.counters[4 + 2 * ph], 1ull);
+            atomicAdd(&a.counters[5 + 2 * ph], (unsigned long long)served);
             atomicAdd(&a.counters[10], (unsigned long long)alive);
         }
-
-        if (phase == ST_RUN) {
+        if (ph == ST_SHADE) { phase = ph; break; }
+        if (ph == ST_RUN) {
             // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
             const int leave_at = n_run - max(1, n_run >> a.run_shift);
             bool walking = (k - 1u) < (NL - 1u);
@@ -494,7 +499,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 if (COUNT && a.census && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)still); }
                 if (still <= leave_at) break;
             }
-        } else if (phase == ST_LEAF) {
+        } else {
             if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
                 int2 tg;
@@ -520,7 +525,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     pending = (pending >> up) ^ 1u;
                 }
             }
-        } else {
+        }
+      }
+      if (phase < 0) break;
+      {
+        {
             if ((k == 0u) & !finished) {
                 // One Philox loop serves every lane of the phase, whatever it needs the block for:
                 //   K_VEC  an attempt of random_unit_vector (lambertian, metal)     vec3.h:145-152
@@ -681,6 +690,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 }
             }
         }
+      }
     }
 }
 
