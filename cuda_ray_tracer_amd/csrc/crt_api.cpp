@@ -48,7 +48,9 @@ struct crt_context {
     bool count_stats = false;
     bool census = false;
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
-    int sched = 1, leaf_num = 4, shade_num = 11, run_shift = 1;
+    int sched = 1, leaf_num = 3, shade_num = 12, run_shift = 1;
+    int persist = 1, unit_samples = 0;  // persistent waves; samples per unit (0: chosen per launch)
+    int num_cus = 256;
 };
 
 namespace {
@@ -98,6 +100,9 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_LDS_LIMIT")) ctx->lds_limit = size_t(atol(b));
     if (const char* b = getenv("CRT_LEAF_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->leaf_num = v; }
     if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
+    if (const char* b = getenv("CRT_PERSIST")) ctx->persist = atoi(b) != 0;
+    if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
         false) {
@@ -277,18 +282,24 @@ static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int
 int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
                           int32_t max_depth, int64_t* d_sums, void* stream_) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    const int ns_ = nsamples;
     if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_accumulate: d_sums is NULL");
     // LDS image of the scene (render_kernel): spheres, and for a BVH world the pair records (simple
     // loop, 64 B per pair) or the sign-sorted plane arrays + leaf tags (scheduled, 96 B + 4 B per pair)
     const bool scheduled = world == CRT_WORLD_BVH && ctx->sched;
     const size_t L = size_t(ctx->num_leaves);
-    size_t scene_bytes = 32 * size_t(ctx->n);
+    size_t scene_bytes = (scheduled && !CRT_SCHED_SPHERES_IN_LDS) ? 0 : 32 * size_t(ctx->n);
     if (world == CRT_WORLD_BVH) scene_bytes += scheduled ? 96 * L + 16 * ((L - L / 2 + 1) / 2) : 64 * L;
     const bool in_lds = scene_bytes <= ctx->lds_limit;
     // workgroup size: 24 waves per CU (6 per SIMD at <= 80 VGPRs) from as many workgroups as the
     // 160 KB of LDS hold
     int block = ctx->block;
-    if (block == 0) block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
+    if (block == 0) {
+        if (scheduled && ctx->persist)  // + 1568 B of LDS per wave: two 12-wave workgroups per CU up to a 60 KB scene image
+            block = !in_lds ? 512 : (scene_bytes <= 60 * 1024 ? 768 : 1024);
+        else
+            block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
+    }
     crt_render_args a;
     memset(&a, 0, sizeof a);
     if (int rc = fill_args(ctx, world, block, sample_offset, nsamples, max_depth, (unsigned long long*)d_sums, a)) return rc;
@@ -296,10 +307,32 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     hipStream_t stream = (hipStream_t)stream_;
     const int nw = block / 64;
     const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
-    const int tiles_per_group = scheduled ? a.tiles_per_wg : nw;
-    const int grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
     size_t lds = in_lds ? scene_bytes : 0;
-    if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
+    int grid;
+    if (scheduled && ctx->persist) {
+        // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
+        // wave pulling (tile, sample chunk) units; units sized for about 64 per wave, 4..64 samples each
+        lds += size_t(nw) * 196 * 8;  // per wave: one tile of accumulators + its unit state
+        int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
+        const int by_waves = 28 / nw;  // 7 waves per SIMD at <= 72 VGPRs
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * nw;
+        int us = ctx->unit_samples;
+        if (us == 0) { us = int(int64_t(ns_) * tiles / (64 * resident_waves)); us = us < 4 ? 4 : (us > 64 ? 64 : us); }
+        a.persist = 1;
+        a.unit_samples = us;
+        a.unit_chunks = (ns_ + us - 1) / us;
+        const int64_t units = tiles * a.unit_chunks;
+        if (units > (1ll << 31) - 1) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^31-1 work units (split the sample range)");
+        a.n_units = int(units);
+        const int64_t wgs = (units + nw - 1) / nw;
+        grid = int(wgs < int64_t(ctx->num_cus) * per_cu ? wgs : int64_t(ctx->num_cus) * per_cu);
+    } else {
+        const int tiles_per_group = scheduled ? a.tiles_per_wg : nw;
+        grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
+        if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
+    }
     CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));

@@ -29,6 +29,11 @@
 #define CRT_MAT_TYPE_SHIFT 28
 #define CRT_MAT_ID_MASK 0x0fffffff
 
+// scheduled kernel: sphere records staged in LDS (1) or read from HBM through L1/L2 (0)
+#ifndef CRT_SCHED_SPHERES_IN_LDS
+#define CRT_SCHED_SPHERES_IN_LDS 0
+#endif
+
 struct crt_dev_camera {
     float center[3], p00[3], du[3], dv[3], ddu[3], ddv[3];
     float defocus_angle;
@@ -52,8 +57,12 @@ struct crt_render_args {
     int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
     int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
     int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
+    int persist;             // 1: persistent waves pulling (tile, sample chunk) units from counters[15]
+    int unit_samples;        // persistent: samples per unit (1..64)
+    int unit_chunks;         // persistent: units per tile = ceil(ns / unit_samples)
+    int n_units;             // persistent: tiles_x * tiles_y * unit_chunks
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
-    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests
+    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit
 };
 
 #endif

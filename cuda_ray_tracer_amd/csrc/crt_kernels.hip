@@ -379,12 +379,67 @@ __device__ __forceinline__ unsigned long long to_fixed(float r) {
 enum { ST_RUN = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3 };
 
 struct wg_pool {
-    unsigned long long* acc;  // LDS: [64 * T][3]
+    unsigned long long* acc;  // LDS: [64 * T][3]; PERSIST: this wave's [64][3]
     uint32_t* counter;        // LDS: next unassigned item
     const int2* origin;       // LDS: pixel origin (x, y) of each of the T tiles; x < 0: tile outside the frame
     uint32_t total;           // 64 * T * ns
     int shift;                // log2(64 * T)
 };
+
+// Persistent waves (PERSIST).  The frame is cut into units = (8x8 tile, chunk of `unit_samples`
+// samples); a wave takes the next unit from a global counter whenever its lanes have used up the
+// items (pixel, sample) of the current one, and exits when the counter runs past the last unit.
+// Nothing is shared between waves, so there is no barrier and no workgroup-wide tail.  The wave
+// keeps ONE tile of accumulators in LDS: on a unit switch it flushes them to the frame (global
+// 64-bit atomics) and the paths of the old unit that are still in flight (at most 64) add their
+// radiance to the frame directly when they end.  Integer sums: the order does not matter.
+// The wave's unit state lives in LDS next to its accumulators (8 dwords, wave-private, read and
+// written by all active lanes with identical values), not in registers: it is touched once per
+// shade phase, and the walking loop keeps its register budget.
+enum { U_NITEMS = 0, U_NEXT = 1, U_EPOCH = 2, U_FLAGS = 3, U_OX = 4, U_OY = 5, U_SBASE = 6 };  // U_FLAGS: 1 have, 2 drained
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ void unit_flush(const crt_render_args& a, unsigned long long* acc, const uint32_t* ust, int lane) {
+    const int ox = (int)uniform(ust[U_OX]), oy = (int)uniform(ust[U_OY]);
+    // the 192 accumulators are dealt round-robin to whichever lanes are active here
+    const unsigned long long m_act = __ballot(true);
+    const int n_act = __popcll(m_act);
+    const int first = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
+    for (int e = first; e < 192; e += n_act) {
+        const unsigned long long q = acc[e];
+        acc[e] = 0ull;
+        const int pix = e / 3, c = e - 3 * pix;
+        const int px = ox + (pix & 7), py = oy + (pix >> 3);
+        if (q != 0ull && px < a.cam.width && py < a.cam.height)
+            atomicAdd(&a.sums[3 * ((size_t)py * a.cam.width + px) + c], q);
+    }
+}
+
+// flush the current unit and take the next one from the global counter (any set of active lanes)
+__device__ __forceinline__ void unit_next(const crt_render_args& a, unsigned long long* acc, uint32_t* ust, int lane) {
+    if (uniform(ust[U_FLAGS]) & 1u) unit_flush(a, acc, ust, lane);
+    uint32_t u = 0;
+    const unsigned long long m_act = __ballot(true);
+    if (lane == __builtin_ctzll(m_act)) u = (uint32_t)atomicAdd(&a.counters[15], 1ull);
+    u = uniform(u);  // readfirstlane: the first active lane is the one that asked
+    ust[U_NEXT] = 0u;
+    if (u >= (uint32_t)a.n_units) {
+        // no unit left: the paths still in flight belong to a flushed tile, like after any switch
+        ust[U_FLAGS] = 2u; ust[U_NITEMS] = 0u;
+        ust[U_EPOCH] = uniform(ust[U_EPOCH]) + 1u;
+    } else {
+        const uint32_t tile = u / (uint32_t)a.unit_chunks, chunk = u - tile * (uint32_t)a.unit_chunks;
+        const uint32_t ty = tile / (uint32_t)a.tiles_x, tx = tile - ty * (uint32_t)a.tiles_x;
+        const uint32_t first = chunk * (uint32_t)a.unit_samples;
+        const uint32_t left = (uint32_t)a.ns - first;
+        ust[U_OX] = tx * 8u; ust[U_OY] = ty * 8u;
+        ust[U_SBASE] = (uint32_t)a.s0 + first;
+        ust[U_NITEMS] = 64u * (left < (uint32_t)a.unit_samples ? left : (uint32_t)a.unit_samples);
+        ust[U_EPOCH] = uniform(ust[U_EPOCH]) + 1u;
+        ust[U_FLAGS] = 1u;
+    }
+}
 
 // Scene access of the walking loop.  In LDS (IN_LDS) the child boxes are stored once per ray
 // direction sign: array 2*axis + (dir[axis] < 0) holds, for pair k, (near_L, far_L, near_R, far_R) =
@@ -399,7 +454,7 @@ struct walk_scene {
     uint32_t L;               // num_leaves
 };
 
-template <bool IN_LDS, bool COUNT>
+template <bool IN_LDS, bool COUNT, bool PERSIST>
 __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const walk_scene& ws, const float4* spheres,
                                                     const float4* mats, const wg_pool& pool, uint32_t& n_rays,
                                                     uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests) {
@@ -423,6 +478,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     uint32_t k = 0, pending = 0, slot = 0;
     uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: byte offset of this ray's plane arrays (+ base)
     bool fresh = true, exact = false, finished = false;
+    uint32_t* ust = (uint32_t*)(pool.acc + 192);  // PERSIST: the wave's unit state, behind its accumulators
 
     for (;;) {
       // The scheduler, the walking phase and the sphere phase form an inner loop of their own: it
@@ -572,16 +628,51 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         }
                     } else {
                         const v3 rad = sky(p);
-                        atomicAdd(&pool.acc[3 * slot + 0], to_fixed(rad.x));
-                        atomicAdd(&pool.acc[3 * slot + 1], to_fixed(rad.y));
-                        atomicAdd(&pool.acc[3 * slot + 2], to_fixed(rad.z));
+                        if (PERSIST && (slot >> 6) != ust[U_EPOCH]) {
+                            // the path outlived its unit, whose tile has been flushed: straight to the frame
+                            unsigned long long* out = a.sums + 3 * (size_t)rs.pixel;
+                            atomicAdd(&out[0], to_fixed(rad.x)); atomicAdd(&out[1], to_fixed(rad.y)); atomicAdd(&out[2], to_fixed(rad.z));
+                        } else {
+                            const uint32_t sl = PERSIST ? (slot & 63u) : slot;
+                            atomicAdd(&pool.acc[3 * sl + 0], to_fixed(rad.x));
+                            atomicAdd(&pool.acc[3 * sl + 1], to_fixed(rad.y));
+                            atomicAdd(&pool.acc[3 * sl + 2], to_fixed(rad.z));
+                        }
                         ++n_samples;
                         fresh = true;
                     }
                 }
                 // lanes without a path take the next items of the workgroup's pool
                 int px = 0, py = 0;
-                const unsigned long long m_need = __ballot(fresh);
+                if (PERSIST) {
+                    // at most two passes: the rest of the current unit, then the head of the next one
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const unsigned long long m_need = __ballot(fresh);
+                        if (m_need == 0) break;
+                        if (uniform(ust[U_NEXT]) >= uniform(ust[U_NITEMS]) && !(uniform(ust[U_FLAGS]) & 2u)) {
+                            unit_next(a, pool.acc, ust, lane);
+                        }
+                        if (uniform(ust[U_FLAGS]) & 2u) { if (fresh) finished = true; break; }
+                        const uint32_t next_item = uniform(ust[U_NEXT]), n_items = uniform(ust[U_NITEMS]);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+                        const uint32_t avail = n_items - next_item, need = (uint32_t)__popcll(m_need);
+                        if (fresh && rank < avail) {
+                            const uint32_t item = next_item + rank;
+                            slot = (item & 63u) | (uniform(ust[U_EPOCH]) << 6);
+                            px = (int)uniform(ust[U_OX]) + (int)(item & 7u); py = (int)uniform(ust[U_OY]) + (int)((item >> 3) & 7u);
+                            if (px < a.cam.width && py < a.cam.height) {
+                                rs.pixel = (uint32_t)(py * a.cam.width + px);
+                                rs.sample = uniform(ust[U_SBASE]) + (item >> 6);
+                                rs.event = 0;
+                                kind = K_CAM;
+                                fresh = false;
+                            }  // else: an item outside the frame; ask again
+                        }
+                        ust[U_NEXT] = next_item + (need < avail ? need : avail);
+                    }
+                }
+                const unsigned long long m_need = PERSIST ? 0ull : __ballot(fresh);
                 if (m_need != 0) {
                     const int leader = __builtin_ctzll(m_need);
                     uint32_t first = 0;
@@ -692,10 +783,13 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         }
       }
     }
+    if (PERSIST && (uniform(ust[U_FLAGS]) & 1u)) unit_flush(a, pool.acc, ust, lane);
 }
 
 // ---------------------------------------------------------------------------------------
-template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, bool SCHED>
+// SCHED: 0 = simple per-lane loop, 1 = wave-scheduled with a workgroup item pool, 2 = wave-scheduled
+// persistent waves
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, int SCHED>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) {
     extern __shared__ float4 smem[];
     constexpr int NW = BLOCK / 64;
@@ -707,7 +801,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     const int L = a.num_leaves;
     const int leaf_parents = L >> 1, n_tagrec = L - leaf_parents;  // pairs [leaf_parents, L) hold sphere tags
     const int np = !(IN_LDS && WORLD == 1) ? 0 : (SCHED ? 6 * L + (n_tagrec + 1) / 2 : 4 * L);
-    const int nsph = IN_LDS ? 2 * a.n : 0;
+    const int nsph = (IN_LDS && !(WORLD == 1 && SCHED && !CRT_SCHED_SPHERES_IN_LDS)) ? 2 * a.n : 0;
     walk_scene ws;
     ws.pairs = pairs; ws.axes = nullptr; ws.leaf_tags = nullptr; ws.L = (uint32_t)L;
     if (IN_LDS) {
@@ -729,13 +823,23 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
             for (int i = threadIdx.x; i < np; i += BLOCK) s_pairs[i] = pairs[i];
             pairs = s_pairs;
         }
-        for (int i = threadIdx.x; i < nsph; i += BLOCK) s_spheres[i] = spheres[i];
-        spheres = s_spheres;
+        if (nsph) {
+            for (int i = threadIdx.x; i < nsph; i += BLOCK) s_spheres[i] = spheres[i];
+            spheres = s_spheres;
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
 
-    if (WORLD == 1 && SCHED) {
+    if (WORLD == 1 && SCHED == 2) {
+        // per wave: 192 accumulators + 4 words (8 dwords) of unit state, all zero at the start
+        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + 196 * wave;
+        for (int i = lane; i < 196; i += 64) acc[i] = 0ull;
+        __syncthreads();  // the scene image is complete; from here on the waves run independently
+        wg_pool pool;
+        pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0;
+        trace_bvh_scheduled<IN_LDS, COUNT, true>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
+    } else if (WORLD == 1 && SCHED == 1) {
         const int T = a.tiles_per_wg;  // power of two
         unsigned long long* acc = (unsigned long long*)(smem + np + nsph);
         int2* origin = (int2*)(acc + 192 * T);
@@ -752,7 +856,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         pool.acc = acc; pool.counter = counter; pool.origin = origin;
         pool.shift = 6 + (31 - __builtin_clz((unsigned)T));
         pool.total = (uint32_t)a.ns << pool.shift;
-        trace_bvh_scheduled<IN_LDS, COUNT>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
+        trace_bvh_scheduled<IN_LDS, COUNT, false>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
         __syncthreads();
         for (int i = threadIdx.x; i < 192 * T; i += BLOCK) {
             const unsigned long long q = acc[i];
@@ -863,7 +967,7 @@ __global__ __launch_bounds__(64) void trace_samples_kernel(const crt_render_args
     segments[i] = segs;
 }
 
-template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, bool SCHED>
+template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, int SCHED>
 hipError_t launch_sched(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
     auto k = render_kernel<WORLD, IN_LDS, COUNT, BLOCK, SCHED>;
     if (lds_bytes > 48 * 1024) {
@@ -876,8 +980,9 @@ hipError_t launch_sched(const crt_render_args& a, int grid, size_t lds_bytes, hi
 
 template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
 hipError_t launch_one(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
-    if (WORLD == 1 && a.sched) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1)>(a, grid, lds_bytes, stream);
-    return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, false>(a, grid, lds_bytes, stream);
+    if (WORLD == 1 && a.sched && a.persist) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1 ? 2 : 0)>(a, grid, lds_bytes, stream);
+    if (WORLD == 1 && a.sched) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1 ? 1 : 0)>(a, grid, lds_bytes, stream);
+    return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, 0>(a, grid, lds_bytes, stream);
 }
 
 template <int WORLD, bool IN_LDS, bool COUNT>
