@@ -168,13 +168,15 @@ def main():
         roofline = {
             "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tflops / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-            "kernel": "render_kernel<WORLD=BVH, IN_LDS, COUNT=0, BLOCK=512, SCHED=1>", "kernel_ms": kavg * 1e3,
+            "kernel": "render_kernel<WORLD=BVH, IN_LDS=1, COUNT=0, BLOCK=768, SCHED=2 (persistent waves)>", "kernel_ms": kavg * 1e3,
             "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
             "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
             "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
-            "note": "not a dense contraction (no MFMA) and the 48 KB scene (child-pair records + spheres) is LDS-resident (HBM traffic ~0): "
-                    "the bound is fp32 VALU issue under wave64 divergence; peak = 157.3 TFLOP/s fp32 vector "
-                    "(= the f32-input MFMA dense peak); scene_fetch_GBs is the algorithmic LDS fetch rate",
+            "note": "not a dense contraction (no MFMA); the BVH (50 KB of sign-sorted box planes + leaf tags) is LDS-resident and the "
+                    "15 KB of spheres stay in L1/L2 (HBM traffic = the frame only): the bound is fp32 VALU issue under wave64 "
+                    "divergence; peak = 157.3 TFLOP/s fp32 vector (= the f32-input MFMA dense peak); flops_per_ray is the "
+                    "algorithmic count of SURVEY.md 8(d) (50 I + 45 S + 60), scene_fetch_GBs the algorithmic scene fetch rate "
+                    "(64 I + 32 S bytes per ray)",
         }
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is
         # the rocprofv3 FETCH_SIZE + WRITE_SIZE measurement of the same launch committed under profiles/
@@ -207,11 +209,13 @@ def main():
         if args.config == "c4":
             out["config"]["workload"] = (f"synthetic {scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
                                          f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
-            roofline.update({"bound": "hbm", "achieved": roofline["scene_fetch_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": roofline["scene_fetch_GBs"] / HBM_PEAK_GBS,
-                             "kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=512, SCHED=1>",
-                             "note": "scene (67 MB child-pair records + 32 MB spheres) is read from HBM/Infinity Cache by "
-                                     "random access; achieved = algorithmic bytes (64 I + 32 S per ray) / kernel time"})
+            hbm_gbs = (roofline["traffic"] / kavg / 1e9) if roofline["traffic"] else None
+            roofline.update({"kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=512, SCHED=2 (persistent waves)>",
+                             "hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+                             "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
+                                     "256 MB Infinity Cache: measured HBM traffic (PMC) is ~3% of the algorithmic bytes "
+                                     "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak), so the "
+                                     "bound stays fp32 VALU issue like C2; achieved/peak as for C2"})
         if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(args, args.seed)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
