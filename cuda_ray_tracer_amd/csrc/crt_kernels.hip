@@ -1,13 +1,13 @@
 // crt_kernels.hip -- the hot path, hand-written for gfx950 (CDNA4, wave64).
 //
-// A workgroup owns a few 8x8 pixel tiles and all samples of them; lanes pull (pixel, sample)
-// work items from a counter in LDS and are scheduled wave-wide by traversal phase (see
+// Persistent waves pull (8x8 tile, sample chunk) units from a global counter; lanes take (pixel,
+// sample) items of their wave's unit and are scheduled wave-wide by traversal phase (see
 // trace_bvh_scheduled).  Radiance is accumulated in 64-bit fixed point, so the image does not
 // depend on scheduling, launch geometry or GPU count -- it is deterministic by construction.
 //
-// The scene (child-pair BVH records and spheres; 48 KB for the reference's random-spheres
-// scene) is staged into LDS once per workgroup; scenes that do not fit
-// are read from HBM through L1/L2.
+// The BVH (sign-sorted box planes + leaf tags; 50 KB for the reference's random-spheres scene)
+// is staged into LDS once per workgroup, spheres and materials are read through L1/L2; scenes
+// that do not fit are read from HBM / Infinity Cache through L1/L2 by the same kernel.
 //
 // Arithmetic contract: every fp32 operation is one IEEE rounding in the order the
 // reference's C++ expressions give (no contraction, correctly rounded / and sqrt), so a
