@@ -96,8 +96,11 @@ def main():
     t_setup0 = time.perf_counter()
     r = crt.Renderer(local_rank, args.seed)
     scene = crt.scene_random(args.scene_seed, half, ground)
+    t_scene = time.perf_counter() - t_setup0
     r.upload_scene(scene)
-    num_nodes = r.build_bvh(17)
+    t_bvh0 = time.perf_counter()
+    num_nodes = r.build_bvh(17)   # GPU builder (crt_bvh.hip); synchronous
+    t_bvh = time.perf_counter() - t_bvh0
     cam = crt.camera(args.width, args.spp, **cam_kw)
     r.set_camera(cam)
     torch.cuda.synchronize()
@@ -203,6 +206,7 @@ def main():
             "msamples_per_s": samples_step * args.steps / elapsed / 1e6,
             "rays_per_step": rays_step, "segments_per_sample": rays_step / samples_step,
             "time_to_image_ms": t_image * 1e3, "setup_ms": t_setup * 1e3,
+            "scene_generation_ms": t_scene * 1e3, "bvh_build_ms": t_bvh * 1e3,
             "image_mean": float(img.mean()),
             "roofline": roofline,
         }

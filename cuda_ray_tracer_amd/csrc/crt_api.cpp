@@ -13,6 +13,7 @@
 
 #include "../../include/crt_hip.h"
 #include "crt_host.h"
+#include "crt_bvh.h"
 #include "crt_launch.h"
 
 struct crt_context {
@@ -28,6 +29,9 @@ struct crt_context {
     bool have_cam = false;
     // device
     void* d_pairs = nullptr;
+    crt_bvh_node* d_nodes = nullptr;  // GPU builder: the node array (ctx->nodes is filled from it on demand)
+    double bvh_seconds = 0;
+    int bvh_host = 0;  // CRT_BVH_HOST=1: build on the host (crt_host.cpp) instead of the GPU (crt_bvh.hip)
     void* d_spheres = nullptr;
     void* d_mats = nullptr;
     float* d_fb = nullptr;
@@ -101,6 +105,7 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_LEAF_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->leaf_num = v; }
     if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
     if (const char* b = getenv("CRT_PERSIST")) ctx->persist = atoi(b) != 0;
+    if (const char* b = getenv("CRT_BVH_HOST")) ctx->bvh_host = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -122,7 +127,7 @@ int crt_destroy(crt_context* ctx) {
     if (!ctx) return CRT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->d_pairs, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_sums, ctx->d_counters, ctx->d_px, ctx->d_py,
+    void* bufs[] = {ctx->d_pairs, ctx->d_nodes, ctx->d_spheres, ctx->d_mats, ctx->d_fb, ctx->d_sums, ctx->d_counters, ctx->d_px, ctx->d_py,
                     ctx->d_smp, ctx->d_seg, ctx->d_ray7, ctx->d_rgb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (hipEvent_t e : ctx->ev_ring) if (e) (void)hipEventDestroy(e);
@@ -178,6 +183,7 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
     if (ctx->d_spheres) { (void)hipFree(ctx->d_spheres); ctx->d_spheres = nullptr; }
     if (ctx->d_mats) { (void)hipFree(ctx->d_mats); ctx->d_mats = nullptr; }
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+    if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
     ctx->nodes.clear(); ctx->num_leaves = 0;
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_spheres, sph.size() * sizeof(float)));
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_mats, mats.size() * sizeof(float)));
@@ -196,7 +202,36 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
     if (crt::bvh_depth(ctx->n) > 28) return fail(ctx, CRT_ERR_TOO_LARGE, "crt_build_bvh: tree deeper than 28 levels (the traversal keeps one bit per level in 32)");
-    const int L = 1 << crt::bvh_depth(ctx->n);
+    const int depth = crt::bvh_depth(ctx->n);
+    const int L = 1 << depth;
+    if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+    if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
+    ctx->nodes.clear();
+    if (!ctx->bvh_host) {
+        // GPU builder (crt_bvh.hip): boxes and the axis table come from the host code both builders share
+        const size_t n = size_t(ctx->n);
+        std::vector<float> boxes(6 * n);
+        std::vector<uint8_t> axis(2 * n - 1);
+        crt::sphere_boxes(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), boxes.data());
+        crt::axis_table(ctx->n, axis_seed, axis.data());
+        float* d_boxes = nullptr; uint8_t* d_axis = nullptr;
+        hipError_t e = hipMalloc((void**)&d_boxes, boxes.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_axis, axis.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_nodes, (2 * size_t(L) - 1) * sizeof(crt_bvh_node));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_pairs, 16 * size_t(L) * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_axis, axis.data(), axis.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = crt_gpu_bvh_build(ctx->n, depth, d_boxes, d_axis, ctx->d_nodes, (float*)ctx->d_pairs, nullptr);
+        (void)hipFree(d_boxes); (void)hipFree(d_axis);
+        if (e != hipSuccess) {
+            if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+            if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
+            return fail(ctx, CRT_ERR_HIP, std::string("crt_build_bvh (GPU builder): ") + hipGetErrorString(e));
+        }
+        ctx->num_leaves = L;
+        if (num_nodes_out) *num_nodes_out = int32_t(2 * size_t(L) - 1);
+        return CRT_OK;
+    }
     ctx->nodes.resize(2 * size_t(L) - 1);
     crt::bvh_build(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), axis_seed, ctx->nodes.data());
     // child-pair records (crt_device.h): record k (1-based heap) holds nodes 2k-1, 2k (0-based)
@@ -223,7 +258,6 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
         if (tag_of(l) == CRT_TAG_EMPTY) { q[0] = q[1] = q[4] = q[5] = q[8] = q[9] = BIG; }
         if (tag_of(r) == CRT_TAG_EMPTY) { q[2] = q[3] = q[6] = q[7] = q[10] = q[11] = BIG; }
     }
-    if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, pairs.size() * sizeof(float)));
     CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->num_leaves = L;
@@ -233,9 +267,16 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
 
 int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity) {
     if (!ctx || !out) return CRT_ERR_INVALID_ARGUMENT;
-    if (ctx->nodes.empty()) return CRT_ERR_STATE;
-    if (size_t(capacity) < ctx->nodes.size()) return CRT_ERR_TOO_LARGE;
-    memcpy(out, ctx->nodes.data(), ctx->nodes.size() * sizeof(crt_bvh_node));
+    if (ctx->num_leaves < 1) return CRT_ERR_STATE;
+    const size_t count = 2 * size_t(ctx->num_leaves) - 1;
+    if (size_t(capacity) < count) return CRT_ERR_TOO_LARGE;
+    if (ctx->d_nodes) {  // GPU builder: straight from the device array
+        if (hipSetDevice(ctx->device) != hipSuccess ||
+            hipMemcpy(out, ctx->d_nodes, count * sizeof(crt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
+            return CRT_ERR_HIP;
+        return CRT_OK;
+    }
+    memcpy(out, ctx->nodes.data(), count * sizeof(crt_bvh_node));
     return CRT_OK;
 }
 

@@ -175,22 +175,27 @@ int bvh_depth(int n) {
 // of s primitives makes 2s-1 calls in total, so the call on [start, start+span) with draw
 // index d has children at d+1 and d+2*floor(span/2): the recursion is replayed with an
 // explicit work list and plain index sorting.
+void sphere_boxes(int n, const float* center, const float* motion, const float* radius, float* boxes) {
+    for (int i = 0; i < n; ++i) sphere_box(center + 3 * size_t(i), motion + 3 * size_t(i), radius[i], boxes + 6 * size_t(i));
+}
+
+// minstd_rand + uniform_int_distribution<int>(0,2), as thrust maps it
+void axis_table(int n, uint32_t axis_seed, uint8_t* axis) {
+    uint64_t x = axis_seed % 2147483647u;
+    if (x == 0) x = 1;
+    for (size_t i = 0; i < 2 * size_t(n) - 1; ++i) {
+        x = (x * 48271u) % 2147483647u;
+        axis[i] = uint8_t(int(double(uint32_t(x) - 1u) / 2147483646.0 * 3.0));
+    }
+}
+
 int bvh_build(int n, const float* center, const float* motion, const float* radius, uint32_t axis_seed,
               crt_bvh_node* nodes) {
     if (n <= 0) return 0;
     std::vector<float> boxes(6 * size_t(n));
-    for (int i = 0; i < n; ++i) sphere_box(center + 3 * i, motion + 3 * i, radius[i], &boxes[6 * size_t(i)]);
-
-    // minstd_rand + uniform_int_distribution<int>(0,2), as thrust maps it
+    sphere_boxes(n, center, motion, radius, boxes.data());
     std::vector<uint8_t> axis(2 * size_t(n) - 1);
-    {
-        uint64_t x = axis_seed % 2147483647u;
-        if (x == 0) x = 1;
-        for (auto& ax : axis) {
-            x = (x * 48271u) % 2147483647u;
-            ax = uint8_t(int(double(uint32_t(x) - 1u) / 2147483646.0 * 3.0));
-        }
-    }
+    axis_table(n, axis_seed, axis.data());
 
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);

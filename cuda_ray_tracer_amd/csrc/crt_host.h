@@ -13,6 +13,10 @@ int scene_small(float* center, float* motion, float* radius, int32_t* mat_id, in
 int scene_random(uint64_t seed, int half, float ground_radius, float* center, float* motion, float* radius,
                  int32_t* mat_id, int32_t* mat_type, float* albedo, float* param);
 int bvh_depth(int n);
+// the two inputs of the BVH construction that are computed on the host for both builders:
+// sphere boxes (6 floats each, sphere.h:10-25) and the 2n-1 pre-order split axes (bvh.h:144-147,257)
+void sphere_boxes(int n, const float* center, const float* motion, const float* radius, float* boxes);
+void axis_table(int n, uint32_t axis_seed, uint8_t* axis);
 int bvh_build(int n, const float* center, const float* motion, const float* radius, uint32_t axis_seed,
               crt_bvh_node* nodes);
 int64_t write_ppm(const float* fb, int width, int height, char* buf, int64_t cap);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KNOBS = ("CRT_BLOCK", "CRT_SCHED", "CRT_TILES", "CRT_LDS_LIMIT", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_RUN_SHIFT",
-         "CRT_PERSIST", "CRT_UNIT_SAMPLES")
+         "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_BVH_HOST")
 
 
 def _bits_equal(a, b):
@@ -56,6 +56,39 @@ def test_bvh_readback_bit_exact(crt, orc, rnd, small):
         want = np.frombuffer(bytes(onodes), np.uint32).reshape(-1, 9)
         assert np.array_equal(got, want)
         r.close()
+
+
+def _tie_scene(crt, n, seed):
+    """n spheres on a coarse lattice: many equal sort keys (ties), some -0.0 coordinates, a third moving."""
+    rng = np.random.default_rng(seed)
+    center = rng.integers(-3, 4, (n, 3)).astype(np.float32) * np.float32(0.5)
+    center[rng.random((n, 3)) < 0.1] = np.float32(-0.0)
+    motion = np.where(rng.random((n, 1)) < 0.33, rng.integers(-1, 2, (n, 3)), 0).astype(np.float32) * np.float32(0.25)
+    radius = rng.choice(np.array([0.0, 0.25, 0.5, 1.0], np.float32), n)
+    return crt.Scene(center, motion, radius, np.zeros(n, np.int32), [0], [[0.5, 0.5, 0.5]], [0.0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 9, 31, 33, 100, 1000, 4097, 14000])
+def test_gpu_bvh_builder_matches_host_builder(crt, orc, n):
+    """crt_build_bvh (GPU: one stable radix sort per tree level, crt_bvh.hip) against crt_bvh_build_host (the
+    reference's recursion replayed on the host), which tests/test_host_parity.py holds to the oracle: the node
+    array bit for bit, on scenes full of ties; and against the host-built pair records through a render."""
+    for seed, sc in ((n, _tie_scene(crt, n, n)), (0, None)):
+        if sc is None:
+            rng = np.random.default_rng(n)
+            sc = crt.Scene(rng.normal(0, 5, (n, 3)), np.zeros((n, 3)), rng.uniform(0.05, 0.5, n), np.zeros(n, np.int32),
+                           [0], [[0.5, 0.5, 0.5]], [0.0])
+        want = np.frombuffer(bytes(crt.bvh_build_host(sc, 99)), np.uint32).reshape(-1, 9)
+        frames = []
+        for host in (0, 1):
+            r = _renderer(crt, sc, crt.camera(48, 2, lookfrom=(0.0, 1.0, 12.0), focus_dist=12.0), 3, bvh=False,
+                          CRT_BVH_HOST=host)
+            r.build_bvh(99)
+            got = np.frombuffer(bytes(r.bvh_nodes()), np.uint32).reshape(-1, 9)
+            assert np.array_equal(got, want), (n, host)
+            frames.append(r.render(crt.CRT_WORLD_BVH, 2, 0, 8)[0])
+            r.close()
+        assert _bits_equal(frames[0], frames[1])
 
 
 @pytest.mark.parametrize("which,world", [("small", 0), ("small", 1), ("rnd", 0), ("rnd", 1)])
