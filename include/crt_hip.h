@@ -136,7 +136,8 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
                      const float* mat_param);
 
 /* bvh_world::bvh_world(object_list, n), bvh.h:135-192.  axis_seed is 17 in the reference
- * (bvh.h:144).  *num_nodes_out <- 2^(depth+1)-1. */
+ * (bvh.h:144).  *num_nodes_out <- 2^(depth+1)-1.  Built on the GPU (one stable sort per
+ * tree level); the node array equals crt_bvh_build_host's bit for bit. */
 int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out);
 /* read-back of bvh_world::d_nodes (bvh.h:131) for the bit-exact check */
 int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity);
