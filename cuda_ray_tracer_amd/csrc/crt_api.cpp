@@ -53,6 +53,7 @@ struct crt_context {
     bool census = false;
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
     int sched = 1, leaf_num = 3, shade_num = 12, run_shift = 1;
+    int tail_pass = 1;
     int persist = 1, unit_samples = 0;  // persistent waves; samples per unit (0: chosen per launch)
     int num_cus = 256;
 };
@@ -106,6 +107,7 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
     if (const char* b = getenv("CRT_PERSIST")) ctx->persist = atoi(b) != 0;
     if (const char* b = getenv("CRT_BVH_HOST")) ctx->bvh_host = atoi(b) != 0;
+    if (const char* b = getenv("CRT_TAIL_PASS")) ctx->tail_pass = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -336,8 +338,8 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     // 160 KB of LDS hold
     int block = ctx->block;
     if (block == 0) {
-        if (scheduled && ctx->persist)  // + 1568 B of LDS per wave: two 12-wave workgroups per CU up to a 60 KB scene image
-            block = !in_lds ? 512 : (scene_bytes <= 60 * 1024 ? 768 : 1024);
+        if (scheduled && ctx->persist)  // + 2080 B of LDS per wave: two 12-wave workgroups per CU up to a 55 KB scene image
+            block = !in_lds ? 512 : (scene_bytes <= 55 * 1024 ? 768 : 1024);
         else
             block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
     }
@@ -353,7 +355,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     if (scheduled && ctx->persist) {
         // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
         // wave pulling (tile, sample chunk) units; units sized for about 64 per wave, 4..64 samples each
-        lds += size_t(nw) * 196 * 8;  // per wave: one tile of accumulators + its unit state
+        lds += size_t(nw) * 260 * 8;  // per wave: one tile of accumulators, its unit state, 32 block requests
         int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
         const int by_waves = 28 / nw;  // 7 waves per SIMD at <= 72 VGPRs
         if (per_cu > by_waves) per_cu = by_waves;
@@ -362,6 +364,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         int us = ctx->unit_samples;
         if (us == 0) { us = int(int64_t(ns_) * tiles / (64 * resident_waves)); us = us < 4 ? 4 : (us > 64 ? 64 : us); }
         a.persist = 1;
+        a.tail_pass = ctx->tail_pass;
         a.unit_samples = us;
         a.unit_chunks = (ns_ + us - 1) / us;
         const int64_t units = tiles * a.unit_chunks;

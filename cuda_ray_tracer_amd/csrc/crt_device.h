@@ -61,6 +61,7 @@ struct crt_render_args {
     int unit_samples;        // persistent: samples per unit (1..64)
     int unit_chunks;         // persistent: units per tile = ceil(ns / unit_samples)
     int n_units;             // persistent: tiles_x * tiles_y * unit_chunks
+    int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
     unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit
 };

@@ -586,19 +586,25 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       if (phase < 0) break;
       {
         {
-            if ((k == 0u) & !finished) {
+            // The shade phase has three parts: (1) hit record / next work item, lanes in the shade
+            // state only; (2) the Philox block loop, whole wave (lanes that need no block idle or, in
+            // a tail pass, draw blocks for the lanes that do); (3) scatter direction or primary ray.
+            const bool shading = (k == 0u) & !finished;
+            enum { K_NONE = 0, K_VEC = 1, K_U = 2, K_CAM = 3, K_DISK = 4 };
+            int kind = K_NONE, type = -1;
+            v3 nrm = mk(0, 0, 0), base = mk(0, 0, 0);
+            float scale = 0.0f, aux = 0.0f;          // VEC: fuzz / -, dielectric: cos_theta / ri
+            float u0 = 0, u1 = 0, u2 = 0, u3 = 0;    // VEC: p.xyz, lensq; K_U: u; CAM: x_off, y_off, time
+            bool cannot = false;
+            int px = 0, py = 0;
+            float dx = 0.0f, dy = 0.0f;
+            if (shading) {
                 // One Philox loop serves every lane of the phase, whatever it needs the block for:
                 //   K_VEC  an attempt of random_unit_vector (lambertian, metal)     vec3.h:145-152
                 //   K_U    the dielectric's reflect/refract draw                    material.h:78
                 //   K_CAM  the camera block of a new path, then K_DISK              render_with_cuda.h:11-26
                 // Each lane still draws ITS blocks in its own order (event counter per path); only
                 // the wave executes one Philox per iteration instead of one per material loop.
-                enum { K_NONE = 0, K_VEC = 1, K_U = 2, K_CAM = 3, K_DISK = 4 };
-                int kind = K_NONE, type = -1;
-                v3 nrm = mk(0, 0, 0), base = mk(0, 0, 0);
-                float scale = 0.0f, aux = 0.0f;          // VEC: fuzz / -, dielectric: cos_theta / ri
-                float u0 = 0, u1 = 0, u2 = 0, u3 = 0;    // VEC: p.xyz, lensq; K_U: u; CAM: x_off, y_off, time
-                bool cannot = false;
                 if (!fresh) {
                     ++n_rays;
                     if (best_obj >= 0) {
@@ -643,7 +649,6 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                 }
                 // lanes without a path take the next items of the workgroup's pool
-                int px = 0, py = 0;
                 if (PERSIST) {
                     // at most two passes: the rest of the current unit, then the head of the next one
                     for (int pass = 0; pass < 2; ++pass) {
@@ -698,13 +703,64 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         }
                     }
                 }
-                // the shared block loop
-                float dx = 0.0f, dy = 0.0f;
-                while (kind != K_NONE) {
-                    if (COUNT && a.census) {  // block-loop census: iterations (per wave) and lanes served
-                        const unsigned long long m_blk = __ballot(true);
-                        if (lane == __builtin_ctzll(m_blk)) { atomicAdd(&a.counters[13], 1ull); atomicAdd(&a.counters[14], (unsigned long long)__popcll(m_blk)); }
+            }
+            // (2) the shared block loop
+            for (;;) {
+                const unsigned long long m_blk = __ballot(kind != K_NONE);
+                if (m_blk == 0) break;
+                const int n_blk = __popcll(m_blk);
+                if (COUNT && a.census && lane == 0) {  // block-loop census: iterations (per wave) and lanes served
+                    atomicAdd(&a.counters[13], 1ull); atomicAdd(&a.counters[14], (unsigned long long)n_blk);
+                }
+                const unsigned long long m_rej = __ballot(kind == K_VEC || kind == K_DISK);
+                if (PERSIST && m_rej == m_blk && n_blk <= 32 && a.tail_pass) {
+                    // Tail pass.  Only rejection-sampling lanes are left (52% / 79% acceptance per attempt)
+                    // and they are few: the WHOLE wave draws for them, G = 2, 4 or 8 consecutive blocks of
+                    // each lane's stream at once (lane h: the block of requester h / G at its event
+                    // counter + h % G).  A requester takes the first accepted attempt in stream order
+                    // and advances its counter past it, exactly what one block per iteration would
+                    // have done; the blocks drawn beyond it are dropped.
+                    const int g_shift = n_blk <= 8 ? 3 : (n_blk <= 16 ? 2 : 1);
+                    const uint32_t rank = 31u & __builtin_amdgcn_mbcnt_hi((uint32_t)(m_blk >> 32),  // requesters: < n_blk <= 32
+                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m_blk, 0u));
+                    uint4* req = (uint4*)(ust + 8);  // 32 requests of 16 bytes behind the unit state
+                    if (kind != K_NONE) req[rank] = make_uint4(rs.pixel, rs.sample, rs.event, (uint32_t)kind);
+                    const uint32_t hr = (uint32_t)lane >> g_shift, hj = (uint32_t)lane & ((1u << g_shift) - 1u);
+                    bool ok = false;
+                    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+                    if (hr < (uint32_t)n_blk) {
+                        const uint4 q = req[hr];
+                        const uint4 rr = philox4x32_10(q.z + hj, q.y, q.x, 0u, rs.k0, rs.k1);
+                        const float4 b = make_float4(u01(rr.x), u01(rr.y), u01(rr.z), u01(rr.w));
+                        if (q.w == (uint32_t)K_VEC) {
+                            v0 = rf11(b.x); v1 = rf11(b.y); v2 = rf11(b.z);
+                            const float l = v0 * v0 + v1 * v1 + v2 * v2;
+                            ok = 0.0f < l && l <= 1.0f;
+                        } else {
+                            v0 = rf11(b.x); v1 = rf11(b.y);
+                            ok = v0 * v0 + v1 * v1 + 0.0f * 0.0f < 1.0f;
+                            if (!ok) { v0 = rf11(b.z); v1 = rf11(b.w); ok = v0 * v0 + v1 * v1 + 0.0f * 0.0f < 1.0f; }
+                        }
                     }
+                    const unsigned long long m_ok = __ballot(ok);
+                    const uint32_t G = 1u << g_shift;
+                    const uint32_t mine = (uint32_t)(m_ok >> (rank << g_shift)) & ((1u << G) - 1u);  // my G attempts
+                    const uint32_t first = (uint32_t)__builtin_ctz(mine | 0x100u);
+                    const int src = (int)((((rank << g_shift) + (first & (G - 1u))) & 63u) << 2);
+                    const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v0)));
+                    const float w1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v1)));
+                    const float w2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v2)));
+                    if (kind != K_NONE) {
+                        if (mine != 0u) {
+                            rs.event += first + 1u;
+                            if (kind == K_VEC) { u0 = w0; u1 = w1; u2 = w2; u3 = u0 * u0 + u1 * u1 + u2 * u2; }
+                            else { dx = w0; dy = w1; }
+                            kind = K_NONE;
+                        } else {
+                            rs.event += G;
+                        }
+                    }
+                } else if (kind != K_NONE) {
                     const float4 b = rs.next_block();
                     if (kind == K_VEC) {
                         u0 = rf11(b.x); u1 = rf11(b.y); u2 = rf11(b.z);
@@ -723,6 +779,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         }
                     }
                 }
+            }
+            if (shading) {
                 // finish: scatter direction, or the new primary ray
                 if (type >= 0) {
                     v3 dir;
@@ -832,9 +890,9 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     uint32_t n_rays = 0, n_samples = 0, n_pairs = 0, n_tests = 0;
 
     if (WORLD == 1 && SCHED == 2) {
-        // per wave: 192 accumulators + 4 words (8 dwords) of unit state, all zero at the start
-        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + 196 * wave;
-        for (int i = lane; i < 196; i += 64) acc[i] = 0ull;
+        // per wave: 192 accumulators + 8 dwords of unit state (all zero at the start) + 32 block requests
+        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + 260 * wave;
+        for (int i = lane; i < 260; i += 64) acc[i] = 0ull;
         __syncthreads();  // the scene image is complete; from here on the waves run independently
         wg_pool pool;
         pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0;
