@@ -52,7 +52,7 @@ struct crt_context {
     bool count_stats = false;
     bool census = false;
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
-    int sched = 1, leaf_num = 3, shade_num = 12, run_shift = 1;
+    int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
     int persist = 1, unit_samples = 0;  // persistent waves; samples per unit (0: chosen per launch)
     int num_cus = 256;

@@ -561,20 +561,15 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 int2 tg;
                 if (IN_LDS) tg = ws.leaf_tags[k >> 1];
                 else { const float4 q3 = pairs[4 * (k >> 1) + 3]; tg = make_int2(__float_as_int(q3.x), __float_as_int(q3.y)); }
-                const int cand0 = (k & 1u) ? tg.y : tg.x;
-                const int cand1 = (pending & 1u) ? tg.y : -1;
-                {
-                    const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand0), p.r, ray_a, tmin, best_t);
-                    if (COUNT) n_tests += 1;
-                    if (root > 0.0f) { best_t = root; best_obj = cand0; }
-                }
-                if (cand1 >= 0) {
-                    const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand1), p.r, ray_a, tmin, best_t);
-                    if (COUNT) n_tests += 1;
-                    if (root > 0.0f) { best_t = root; best_obj = cand1; }
-                }
-                pending &= ~1u;
-                if (NL == 1u) { k = 0u; }  // the root was the only leaf
+                const int cand = (k & 1u) ? tg.y : tg.x;
+                const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand), p.r, ray_a, tmin, best_t);
+                if (COUNT) n_tests += 1;
+                if (root > 0.0f) { best_t = root; best_obj = cand; }
+                // ONE sphere per lane and phase: a hit sibling (2% of the leaf visits) is the lane's next
+                // leaf, tested in the next sphere phase, instead of a second test that the whole wave
+                // would step through for the one lane that needs it
+                if (pending & 1u) { k ^= 1u; pending &= ~1u; }
+                else if (NL == 1u) { k = 0u; }  // the root was the only leaf
                 else {
                     const int up = __builtin_ctz(pending);
                     k = (k >> up) ^ 1u;
