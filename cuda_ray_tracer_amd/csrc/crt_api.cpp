@@ -50,7 +50,7 @@ struct crt_context {
     int block = 0;  // 0: chosen per launch from the LDS footprint (CRT_BLOCK overrides)
     int tiles_per_wg = 0;  // 0 = auto
     bool count_stats = false;
-    bool census = false;
+    int census = 0;  // 1: scheduler counts, 2: per-phase cycles (internal, tools/tune.py)
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
@@ -110,8 +110,8 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_TAIL_PASS")) ctx->tail_pass = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 24 * sizeof(unsigned long long)) != hipSuccess ||
         false) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
@@ -146,7 +146,7 @@ int crt_set_seed(crt_context* ctx, uint64_t seed) {
 int crt_set_count_stats(crt_context* ctx, int32_t enable) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     ctx->count_stats = enable != 0;
-    ctx->census = enable == 2;  // internal: scheduler census for tools/tune.py
+    ctx->census = enable == 2 ? 1 : (enable == 3 ? 2 : 0);  // internal: scheduler census / phase cycles for tools/tune.py
     return CRT_OK;
 }
 
@@ -377,7 +377,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
         if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     }
-    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 24 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
     CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
@@ -433,7 +433,7 @@ int crt_debug_counters(crt_context* ctx, uint64_t* out16) {
     if (!ctx || !out16) return CRT_ERR_INVALID_ARGUMENT;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
-    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -479,6 +479,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: byte offset of this ray's plane arrays (+ base)
     bool fresh = true, exact = false, finished = false;
     uint32_t* ust = (uint32_t*)(pool.acc + 192);  // PERSIST: the wave's unit state, behind its accumulators
+    // census (COUNT && a.census): shader cycles of this wave per phase, counters[16..21]
+    const bool timing = COUNT && (a.census & 2);
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};  // scheduler, walking, spheres, shade part 1, block loop, shade part 3
+    long long t_mark = timing ? (long long)__builtin_readcyclecounter() : 0;
+#define CRT_LAP(i) do { if (timing) { const long long t_ = (long long)__builtin_readcyclecounter(); tc[i] += (unsigned long long)(t_ - t_mark); t_mark = t_; } } while (0)
 
     for (;;) {
       // The scheduler, the walking phase and the sphere phase form an inner loop of their own: it
@@ -497,12 +502,13 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) ph = ST_SHADE;
         else if (n_run > 0) ph = ST_RUN;
         else ph = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
-        if (COUNT && a.census && lane == 0) {  // scheduler census: iterations and served lanes per phase
+        if (COUNT && (a.census & 1) && lane == 0) {  // scheduler census: iterations and served lanes per phase
             const int served = ph == ST_RUN ? n_run : ph == ST_LEAF ? n_leaf : n_shade;
             atomicAdd(&a.counters[4 + 2 * ph], 1ull);
             atomicAdd(&a.counters[5 + 2 * ph], (unsigned long long)served);
             atomicAdd(&a.counters[10], (unsigned long long)alive);
         }
+        CRT_LAP(0);
         if (ph == ST_SHADE) { phase = ph; break; }
         if (ph == ST_RUN) {
             // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
@@ -543,7 +549,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                     // branch-free successor: descend (left first, right remembered) -- onto a leaf:
                     // hold it for the sphere phase -- or pop the nearest pending right sibling
-                    const bool both = hitL & hitR, any = hitL | hitR;
+                    const bool both = hitL && hitR, any = hitL || hitR;
                     const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
                     const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
                     const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
@@ -552,9 +558,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 }
                 walking = (k - 1u) < (NL - 1u);
                 const int still = __popcll(__ballot(walking));
-                if (COUNT && a.census && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)still); }
+                if (COUNT && (a.census & 1) && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)still); }
                 if (still <= leave_at) break;
             }
+            CRT_LAP(1);
         } else {
             if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
@@ -576,6 +583,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     pending = (pending >> up) ^ 1u;
                 }
             }
+            CRT_LAP(2);
         }
       }
       if (phase < 0) break;
@@ -699,12 +707,13 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                 }
             }
+            CRT_LAP(3);
             // (2) the shared block loop
             for (;;) {
                 const unsigned long long m_blk = __ballot(kind != K_NONE);
                 if (m_blk == 0) break;
                 const int n_blk = __popcll(m_blk);
-                if (COUNT && a.census && lane == 0) {  // block-loop census: iterations (per wave) and lanes served
+                if (COUNT && (a.census & 1) && lane == 0) {  // block-loop census: iterations (per wave) and lanes served
                     atomicAdd(&a.counters[13], 1ull); atomicAdd(&a.counters[14], (unsigned long long)n_blk);
                 }
                 const unsigned long long m_rej = __ballot(kind == K_VEC || kind == K_DISK);
@@ -775,6 +784,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                 }
             }
+            CRT_LAP(4);
             if (shading) {
                 // finish: scatter direction, or the new primary ray
                 if (type >= 0) {
@@ -833,10 +843,14 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     }
                 }
             }
+            CRT_LAP(5);
         }
       }
     }
     if (PERSIST && (uniform(ust[U_FLAGS]) & 1u)) unit_flush(a, pool.acc, ust, lane);
+    if (timing && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.counters[16 + i], tc[i]);
+#undef CRT_LAP
 }
 
 // ---------------------------------------------------------------------------------------

@@ -70,7 +70,7 @@ def main():
             buf.zero_()
             r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
             st = r.stats()
-            c = (C.c_uint64 * 16)()
+            c = (C.c_uint64 * 24)()
             crt.lib().crt_debug_counters(r._ctx, c)
             c = list(c)
             names = ["RUN", "LEAF", "SHADE"]
@@ -78,6 +78,15 @@ def main():
             msg += f" RUN steps {c[11]} ({c[11] / st.rays:.3f}/ray) lanes still walking after a step {c[12] / max(1, c[11]):.1f};"
             msg += f" Philox loop iters {c[13]} ({c[13] / max(1, c[8]):.2f}/shade phase) lanes/iter {c[14] / max(1, c[13]):.1f};"
             msg += f" alive/iter {c[10] / max(1, c[4] + c[6] + c[8]):.1f}"
+            r.set_count_stats(3)  # per-phase shader cycles only (no per-iteration atomics)
+            buf.zero_()
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            st3 = r.stats()
+            t = (C.c_uint64 * 24)()
+            crt.lib().crt_debug_counters(r._ctx, t)
+            tot = max(1, sum(t[16:22]))
+            msg += f" cycles (kernel {st3.kernel_seconds * 1e3:.1f} ms): " + " ".join(
+                f"{nm} {t[16 + j] / tot * 100:.1f}%" for j, nm in enumerate(["sched", "walk", "sphere", "shade1", "blocks", "shade3"]))
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
     for i, v in enumerate(args.variants):
