@@ -357,7 +357,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         // wave pulling (tile, sample chunk) units; units sized for about 64 per wave, 4..64 samples each
         lds += size_t(nw) * 260 * 8;  // per wave: one tile of accumulators, its unit state, 32 block requests
         int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
-        const int by_waves = 28 / nw;  // 7 waves per SIMD at <= 72 VGPRs
+        const int by_waves = 24 / nw;  // 6 waves per SIMD at the kernel's 75 VGPRs
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
         const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * nw;

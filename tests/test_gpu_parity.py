@@ -222,6 +222,20 @@ def test_config2_full_size_region_and_properties(crt, orc, rnd):
     r.close()
 
 
+def test_config2_full_frame_bit_exact_at_high_sample_indices(crt, orc, rnd):
+    """The whole 1200x675 frame of config 2, samples 497..499 of every pixel (the last ones of a 500-spp
+    image, i.e. one rank's tail of a sample split), bit for bit against the oracle."""
+    sc, osc, onodes = rnd
+    seed, W, s0, ns = 1, 1200, 497, 3
+    cam, ocam = crt.camera(W, 500), orc.camera(W, 500)
+    r = _renderer(crt, sc, cam, seed)
+    fb, st = r.render(crt.CRT_WORLD_BVH, ns, s0, 50)
+    sums, ost = orc.render(osc, ocam, seed, s0, ns, 50, onodes, nthreads=16)
+    assert _bits_equal(fb, orc.resolve(sums, ns))
+    assert st.rays == ost[0] and st.samples == 1200 * 675 * ns
+    r.close()
+
+
 def test_scene_in_global_memory_path(crt, orc):
     """A scene too big for LDS (80x80 grid, ~6.3k spheres, 16383 nodes) takes the HBM path."""
     sc, osc = crt.scene_random(4, 40), orc.scene_random(4, 40)
