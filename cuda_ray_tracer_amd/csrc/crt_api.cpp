@@ -54,6 +54,7 @@ struct crt_context {
     size_t lds_limit = 78 * 1024;  // two workgroups per CU
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
+    int top_pairs_max = 1024;  // CRT_TOP_PAIRS
     int persist = 1, unit_samples = 0;  // persistent waves; samples per unit (0: chosen per launch)
     int num_cus = 256;
 };
@@ -107,6 +108,7 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_SHADE_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->shade_num = v; }
     if (const char* b = getenv("CRT_PERSIST")) ctx->persist = atoi(b) != 0;
     if (const char* b = getenv("CRT_BVH_HOST")) ctx->bvh_host = atoi(b) != 0;
+    if (const char* b = getenv("CRT_TOP_PAIRS")) { int v = atoi(b); if (v >= 0 && v <= 2048) ctx->top_pairs_max = v; }
     if (const char* b = getenv("CRT_TAIL_PASS")) ctx->tail_pass = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -336,10 +338,13 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     const bool in_lds = scene_bytes <= ctx->lds_limit;
     // workgroup size: 24 waves per CU (6 per SIMD at <= 80 VGPRs) from as many workgroups as the
     // 160 KB of LDS hold
+    // a scene that stays in HBM still gets the first pair records (the upper tree levels) in LDS
+    int top_pairs = 0;
+    if (scheduled && ctx->persist && !in_lds && ctx->top_pairs_max > 0) { top_pairs = 1; while (2 * top_pairs <= ctx->top_pairs_max && size_t(2 * top_pairs) <= L) top_pairs *= 2; }
     int block = ctx->block;
     if (block == 0) {
         if (scheduled && ctx->persist)  // + 2080 B of LDS per wave: two 12-wave workgroups per CU up to a 55 KB scene image
-            block = !in_lds ? 512 : (scene_bytes <= 55 * 1024 ? 768 : 1024);
+            block = !in_lds ? (top_pairs > 0 ? 768 : 512) : (scene_bytes <= 55 * 1024 ? 768 : 1024);
         else
             block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
     }
@@ -350,7 +355,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     hipStream_t stream = (hipStream_t)stream_;
     const int nw = block / 64;
     const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
-    size_t lds = in_lds ? scene_bytes : 0;
+    size_t lds = in_lds ? scene_bytes : 48 * size_t(top_pairs);
     int grid;
     if (scheduled && ctx->persist) {
         // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
@@ -364,6 +369,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         int us = ctx->unit_samples;
         if (us == 0) { us = int(int64_t(ns_) * tiles / (64 * resident_waves)); us = us < 4 ? 4 : (us > 64 ? 64 : us); }
         a.persist = 1;
+        a.top_pairs = top_pairs;
         a.tail_pass = ctx->tail_pass;
         a.unit_samples = us;
         a.unit_chunks = (ns_ + us - 1) / us;

@@ -61,9 +61,10 @@ struct crt_render_args {
     int unit_samples;        // persistent: samples per unit (1..64)
     int unit_chunks;         // persistent: units per tile = ceil(ns / unit_samples)
     int n_units;             // persistent: tiles_x * tiles_y * unit_chunks
+    int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
-    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit
+    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit [16..21] phase cycles
 };
 
 #endif
