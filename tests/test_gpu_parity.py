@@ -236,6 +236,26 @@ def test_config2_full_frame_bit_exact_at_high_sample_indices(crt, orc, rnd):
     r.close()
 
 
+@pytest.mark.parametrize("vfov", [0.0, 1e-38, 1e-36, 1e-30, 1e-18])
+@pytest.mark.parametrize("env", [dict(), dict(CRT_LDS_LIMIT=0), dict(CRT_SCHED=0)])
+def test_degenerate_ray_directions(crt, orc, rnd, small, vfov, env):
+    """A pinhole camera with a vanishing field of view looking down -z: the x and y components of
+    every primary ray are zero or denormal (vfov 0, 1e-38: 1/d = inf, the literal slab comparisons of
+    aabb.h:48-62 with inf and NaN products) or tiny normals (1e-36 .. 1e-18: reciprocals up to ~1e37, the
+    min/max form with overflowing products).  Frames bit for bit against the oracle."""
+    seed, W, spp = 9, 16, 8
+    for (sc, osc, onodes), lookfrom, lookat in ((small, (0.0, 0.0, 10.0), (0.0, 0.0, -1.0)), (rnd, (0.0, 0.3, 14.0), (0.0, 0.3, 0.0)),
+                                                 (rnd, (4.0, 1.0, 14.0), (4.0, 1.0, 0.0))):
+        kw = dict(vfov=vfov, defocus_angle=0.0, lookfrom=lookfrom, lookat=lookat)
+        cam, ocam = crt.camera(W, spp, **kw), orc.camera(W, spp, **kw)
+        r = _renderer(crt, sc, cam, seed, **env)
+        fb, st = r.render(crt.CRT_WORLD_BVH, spp, 0, 20)
+        sums, ost = orc.render(osc, ocam, seed, 0, spp, 20, onodes, nthreads=4)
+        assert _bits_equal(fb, orc.resolve(sums, spp)), (vfov, lookfrom)
+        assert st.rays == ost[0]
+        r.close()
+
+
 def test_scene_in_global_memory_path(crt, orc):
     """A scene too big for LDS (80x80 grid, ~6.3k spheres, 16383 nodes) takes the HBM path."""
     sc, osc = crt.scene_random(4, 40), orc.scene_random(4, 40)
