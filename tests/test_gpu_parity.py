@@ -256,6 +256,32 @@ def test_degenerate_ray_directions(crt, orc, rnd, small, vfov, env):
         r.close()
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_fuzz_scene_camera_depth(crt, orc, case):
+    """Seeded random configurations: scene size (LDS image or HBM path), camera inside / outside the
+    scene, field of view, defocus, ragged frame sizes, sample offset, depth 1..50 -- frame, ray count
+    and traversal counters bit for bit against the oracle."""
+    rng = np.random.default_rng(1000 + case)
+    half = int(rng.choice([1, 3, 6, 11, 14, 20]))
+    sc, osc = crt.scene_random(100 + case, half), orc.scene_random(100 + case, half)
+    onodes, _ = orc.bvh_build(osc, 17)
+    W = int(rng.choice([9, 33, 57, 97, 130]))
+    spp, s0 = int(rng.choice([1, 3, 9])), int(rng.integers(0, 5000))
+    depth = int(rng.choice([1, 2, 7, 50]))
+    kw = dict(vfov=float(rng.uniform(10, 100)), defocus_angle=float(rng.choice([0.0, 0.6, 3.0])),
+              focus_dist=float(rng.uniform(1, 12)), aspect_ratio=float(rng.choice([1.0, 16.0 / 9.0, 0.7])),
+              lookfrom=tuple(float(x) for x in rng.uniform([-6, 0.3, -6], [6, 3, 6])),
+              lookat=tuple(float(x) for x in rng.uniform([-3, 0, -3], [3, 1, 3])))
+    cam, ocam = crt.camera(W, spp, **kw), orc.camera(W, spp, **kw)
+    r = _renderer(crt, sc, cam, 77 + case)
+    r.set_count_stats(True)
+    fb, st = r.render(crt.CRT_WORLD_BVH, spp, s0, depth)
+    sums, ost = orc.render(osc, ocam, 77 + case, s0, spp, depth, onodes, nthreads=8)
+    assert _bits_equal(fb, orc.resolve(sums, spp)), (case, half, W, spp, s0, depth, kw)
+    assert [st.rays, st.pair_visits, st.sphere_tests, st.samples] == ost
+    r.close()
+
+
 def test_scene_in_global_memory_path(crt, orc):
     """A scene too big for LDS (80x80 grid, ~6.3k spheres, 16383 nodes) takes the HBM path."""
     sc, osc = crt.scene_random(4, 40), orc.scene_random(4, 40)
