@@ -189,6 +189,33 @@ def test_sample_offset_split_and_accumulate(crt, orc, rnd):
     r.close()
 
 
+def test_config5_progressive_4k(crt, orc, rnd):
+    """BASELINE config 5 geometry (3840x2160, progressive): passes of 1 + 2 + 3 samples into one buffer
+    give the sums of a single 6-sample pass exactly; one band of rows bit-exact against the oracle."""
+    import torch
+    sc, osc, onodes = rnd
+    seed, W = 4, 3840
+    cam, ocam = crt.camera(W, 1024), orc.camera(W, 1024)
+    H = cam.image_height
+    assert H == 2160
+    r = _renderer(crt, sc, cam, seed)
+    stream = torch.cuda.current_stream().cuda_stream
+    prog = torch.zeros(H, W, 3, dtype=torch.int64, device="cuda:0")
+    rays = 0
+    for s0, ns in ((1000, 1), (1001, 2), (1003, 3)):
+        r.render_accumulate(crt.CRT_WORLD_BVH, s0, ns, 50, prog.data_ptr(), stream)
+        rays += r.stats().rays
+    once = torch.zeros_like(prog)
+    r.render_accumulate(crt.CRT_WORLD_BVH, 1000, 6, 50, once.data_ptr(), stream)
+    assert rays == r.stats().rays
+    torch.cuda.synchronize()
+    assert torch.equal(prog, once)
+    y0, y1 = 1500, 1504
+    sums, _ = orc.render(osc, ocam, seed, 1000, 6, 50, onodes, region=(0, y0, W, y1), nthreads=8)
+    assert np.array_equal(once[y0:y1].cpu().numpy(), sums[y0:y1])
+    r.close()
+
+
 def test_config2_full_size_region_and_properties(crt, orc, rnd):
     """BASELINE config 2 geometry (1200x675, random spheres, BVH, depth 50): a band of rows
     bit-exact against the oracle, plus size-independent properties on the full frame."""
