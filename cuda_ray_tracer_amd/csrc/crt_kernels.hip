@@ -22,9 +22,8 @@
 
 #pragma clang fp contract(off)
 
-#ifndef CRT_PACKED_SLAB
-#define CRT_PACKED_SLAB 0  // v_pk_add/mul_f32 for the child-pair test: measured 3% SLOWER than scalar on MI355X
-#endif
+// (packed fp32 -- v_pk_add/mul_f32 -- for the slab products was measured 3-5% slower and is not used; the
+// build also turns the SLP vectorizer off for the same reason, see the Makefile)
 
 namespace {
 
@@ -170,25 +169,6 @@ __device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float
     lo = fmaxf(lo, fminf(ty0, ty1)); hi = fminf(hi, fmaxf(ty0, ty1));
     lo = fmaxf(lo, fminf(tz0, tz1)); hi = fminf(hi, fmaxf(tz0, tz1));
     return !(hi <= lo);
-}
-
-// Both children of a pair record at once, with packed fp32 math: {min,max} of one child and one
-// axis sit in adjacent registers (q.xy / q.zw), so (b - o) * inv is one v_pk_add_f32 + one
-// v_pk_mul_f32 per child and axis.  Same operations and roundings as slab_fast.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void slab_pair_fast(float4 q0, float4 q1, float4 q2, v3 o, v3 inv, float lo, float hi,
-                                               bool& hitL, bool& hitR) {
-    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const f2 lx = (f2{q0.x, q0.y} - ox) * ix, rx = (f2{q0.z, q0.w} - ox) * ix;
-    const f2 ly = (f2{q1.x, q1.y} - oy) * iy, ry = (f2{q1.z, q1.w} - oy) * iy;
-    const f2 lz = (f2{q2.x, q2.y} - oz) * iz, rz = (f2{q2.z, q2.w} - oz) * iz;
-    const float loL = fmaxf(fmaxf(lo, fminf(lx.x, lx.y)), fmaxf(fminf(ly.x, ly.y), fminf(lz.x, lz.y)));
-    const float hiL = fminf(fminf(hi, fmaxf(lx.x, lx.y)), fminf(fmaxf(ly.x, ly.y), fmaxf(lz.x, lz.y)));
-    const float loR = fmaxf(fmaxf(lo, fminf(rx.x, rx.y)), fmaxf(fminf(ry.x, ry.y), fminf(rz.x, rz.y)));
-    const float hiR = fminf(fminf(hi, fmaxf(rx.x, rx.y)), fminf(fmaxf(ry.x, ry.y), fmaxf(rz.x, rz.y)));
-    hitL = !(hiL <= loL);
-    hitR = !(hiR <= loR);
 }
 
 __device__ __forceinline__ bool finite3(v3 a) {
