@@ -188,7 +188,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[args.config]
             if W == (1200 if args.config == "c2" else 1920) and world_size == 1:
                 roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_summary.txt"
+                roofline["traffic_source"] = pmc.get("file", "profiles/r01_d_pmc_summary.txt")
         except (OSError, KeyError, ValueError):
             pass
         # time-to-image: set-up + one step + read-back of the finished frame
