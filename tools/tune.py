@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--half", type=int, default=11)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--census", action="store_true")
+    ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--lookfrom", type=float, nargs=3, default=[13, 2, 3])
     ap.add_argument("--ground", type=float, default=1000.0)
     ap.add_argument("--focus", type=float, default=10.0)
@@ -53,7 +54,7 @@ def main():
     for rnd in range(args.rounds + 1):
         for i, r in enumerate(rs):
             buf.zero_()
-            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
             st = r.stats()
             if rnd:
                 times[i].append(st.kernel_seconds * 1e3)
@@ -68,7 +69,7 @@ def main():
         for i, r in enumerate(rs):
             r.set_count_stats(2)
             buf.zero_()
-            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
             st = r.stats()
             c = (C.c_uint64 * 24)()
             crt.lib().crt_debug_counters(r._ctx, c)
@@ -80,7 +81,7 @@ def main():
             msg += f" alive/iter {c[10] / max(1, c[4] + c[6] + c[8]):.1f}"
             r.set_count_stats(3)  # per-phase shader cycles only (no per-iteration atomics)
             buf.zero_()
-            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, 50, buf.data_ptr(), 0)
+            r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
             st3 = r.stats()
             t = (C.c_uint64 * 24)()
             crt.lib().crt_debug_counters(r._ctx, t)
