@@ -51,7 +51,7 @@ struct crt_context {
     int tiles_per_wg = 0;  // 0 = auto
     bool count_stats = false;
     int census = 0;  // 1: scheduler counts, 2: per-phase cycles (internal, tools/tune.py)
-    size_t lds_limit = 78 * 1024;  // two workgroups per CU
+    size_t lds_limit = 126 * 1024;  // scene image that still leaves room for one 16-wave workgroup per CU (55 KB: two 12-wave ones)
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
     int top_pairs_max = 1024;  // CRT_TOP_PAIRS

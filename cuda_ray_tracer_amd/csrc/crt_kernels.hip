@@ -171,6 +171,8 @@ __device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float
     return !(hi <= lo);
 }
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ bool finite3(v3 a) {
     return (fabsf(a.x) < __builtin_huge_valf()) & (fabsf(a.y) < __builtin_huge_valf()) & (fabsf(a.z) < __builtin_huge_valf());
 }
@@ -527,9 +529,22 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     } else {
                         // scene in HBM: the upper levels of the tree (every ray walks them) come from LDS,
                         // which halves the L1 traffic that bounds this instance
-                        float4 q0, q1, q2;
-                        if (k < ws.top_n) { q0 = ws.top[k]; q1 = ws.top[ws.top_n + k]; q2 = ws.top[2u * ws.top_n + k]; }
-                        else { q0 = pairs[4 * k]; q1 = pairs[4 * k + 1]; q2 = pairs[4 * k + 2]; }
+                        // (explicit address spaces: left to itself the compiler merges the two branches into
+                        // flat loads through a selected pointer, which cost twice the time per step)
+                        f4 q0, q1, q2;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        if (k < ws.top_n) {
+                            typedef __attribute__((address_space(3))) const f4 lds_f4;
+                            lds_f4* t = (lds_f4*)(uint32_t)(uintptr_t)ws.top;  // low half of a flat LDS address = LDS offset
+                            q0 = t[k]; q1 = t[ws.top_n + k]; q2 = t[2u * ws.top_n + k];
+                        } else {
+                            typedef __attribute__((address_space(1))) const f4 glb_f4;
+                            glb_f4* g = (glb_f4*)(uintptr_t)pairs;
+                            q0 = g[4 * (size_t)k]; q1 = g[4 * (size_t)k + 1]; q2 = g[4 * (size_t)k + 2];
+                        }
+#else
+                        q0 = q1 = q2 = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
+#endif
                         hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
                         hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
                     }
