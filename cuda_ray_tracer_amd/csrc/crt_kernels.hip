@@ -114,9 +114,26 @@ __device__ __forceinline__ ray_t get_ray(stream& rs, const crt_dev_camera& cam, 
 
 struct sphere_rec { v3 c, mo; float radius; int mat; };
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// The address space is spelled out (LDS or global): a pointer that may be either makes the compiler
+// emit flat loads, which wait on both memory counters and cost about twice as much.
 template <bool IN_LDS>
 __device__ __forceinline__ sphere_rec load_sphere(const float4* spheres, int i) {
-    const float4 a = spheres[2 * i], b = spheres[2 * i + 1];
+    f4 a, b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (IN_LDS) {
+        typedef __attribute__((address_space(3))) const f4 lds_f4;
+        lds_f4* p = (lds_f4*)(uint32_t)(uintptr_t)spheres;  // low half of a flat LDS address = LDS offset
+        a = p[2 * i]; b = p[2 * i + 1];
+    } else {
+        typedef __attribute__((address_space(1))) const f4 glb_f4;
+        glb_f4* p = (glb_f4*)(uintptr_t)spheres;
+        a = p[2 * (size_t)i]; b = p[2 * (size_t)i + 1];
+    }
+#else
+    a = b = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
+#endif
     sphere_rec s;
     s.c = mk(a.x, a.y, a.z); s.radius = a.w;
     s.mo = mk(b.x, b.y, b.z); s.mat = __float_as_int(b.w);
@@ -171,7 +188,6 @@ __device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float
     return !(hi <= lo);
 }
 
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool finite3(v3 a) {
     return (fabsf(a.x) < __builtin_huge_valf()) & (fabsf(a.y) < __builtin_huge_valf()) & (fabsf(a.z) < __builtin_huge_valf());
@@ -570,7 +586,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 if (IN_LDS) tg = ws.leaf_tags[k >> 1];
                 else { const float4 q3 = pairs[4 * (k >> 1) + 3]; tg = make_int2(__float_as_int(q3.x), __float_as_int(q3.y)); }
                 const int cand = (k & 1u) ? tg.y : tg.x;
-                const float root = sphere_root(load_sphere<IN_LDS>(spheres, cand), p.r, ray_a, tmin, best_t);
+                const float root = sphere_root(load_sphere<IN_LDS && CRT_SCHED_SPHERES_IN_LDS>(spheres, cand), p.r, ray_a, tmin, best_t);
                 if (COUNT) n_tests += 1;
                 if (root > 0.0f) { best_t = root; best_obj = cand; }
                 // ONE sphere per lane and phase: a hit sibling (2% of the leaf visits) is the lane's next
@@ -613,7 +629,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     ++n_rays;
                     if (best_obj >= 0) {
                         // hit record: sphere.h:66-70, hittable.h:16-22
-                        const sphere_rec sp = load_sphere<IN_LDS>(spheres, best_obj);
+                        const sphere_rec sp = load_sphere<IN_LDS && CRT_SCHED_SPHERES_IN_LDS>(spheres, best_obj);
                         const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
                         const v3 pos = p.r.o + best_t * p.r.d;
                         const v3 cc = sp.c + p.r.tm * sp.mo;
@@ -638,16 +654,28 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         }
                     } else {
                         const v3 rad = sky(p);
+                        // (explicit address spaces: otherwise the two branches merge into flat atomics on a
+                        // selected pointer)
+                        const unsigned long long fx = to_fixed(rad.x), fy = to_fixed(rad.y), fz = to_fixed(rad.z);
+#if defined(__HIP_DEVICE_COMPILE__)
                         if (PERSIST && (slot >> 6) != ust[U_EPOCH]) {
                             // the path outlived its unit, whose tile has been flushed: straight to the frame
-                            unsigned long long* out = a.sums + 3 * (size_t)rs.pixel;
-                            atomicAdd(&out[0], to_fixed(rad.x)); atomicAdd(&out[1], to_fixed(rad.y)); atomicAdd(&out[2], to_fixed(rad.z));
+                            typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+                            glb_u64* out = (glb_u64*)(uintptr_t)(a.sums + 3 * (size_t)rs.pixel);
+                            __hip_atomic_fetch_add(out + 0, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(out + 1, fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(out + 2, fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else {
+                            typedef __attribute__((address_space(3))) unsigned long long lds_u64;
                             const uint32_t sl = PERSIST ? (slot & 63u) : slot;
-                            atomicAdd(&pool.acc[3 * sl + 0], to_fixed(rad.x));
-                            atomicAdd(&pool.acc[3 * sl + 1], to_fixed(rad.y));
-                            atomicAdd(&pool.acc[3 * sl + 2], to_fixed(rad.z));
+                            lds_u64* out = (lds_u64*)(uint32_t)(uintptr_t)(pool.acc + 3 * sl);  // low half of a flat LDS address
+                            __hip_atomic_fetch_add(out + 0, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(out + 1, fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(out + 2, fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
+#else
+                        (void)fx; (void)fy; (void)fz;  // host pass of the single-source compile: never runs
+#endif
                         ++n_samples;
                         fresh = true;
                     }
