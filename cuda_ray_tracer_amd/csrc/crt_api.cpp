@@ -336,11 +336,11 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     size_t scene_bytes = (scheduled && !CRT_SCHED_SPHERES_IN_LDS) ? 0 : 32 * size_t(ctx->n);
     if (world == CRT_WORLD_BVH) scene_bytes += scheduled ? 96 * L + 16 * ((L - L / 2 + 1) / 2) : 64 * L;
     const bool in_lds = scene_bytes <= ctx->lds_limit;
-    // workgroup size: 24 waves per CU (6 per SIMD at <= 80 VGPRs) from as many workgroups as the
-    // 160 KB of LDS hold
     // a scene that stays in HBM still gets the first pair records (the upper tree levels) in LDS
     int top_pairs = 0;
     if (scheduled && ctx->persist && !in_lds && ctx->top_pairs_max > 0) { top_pairs = 1; while (2 * top_pairs <= ctx->top_pairs_max && size_t(2 * top_pairs) <= L) top_pairs *= 2; }
+    // workgroup size: 24 waves per CU (6 per SIMD at the kernel's 75 VGPRs) from as many workgroups as
+    // the 160 KB of LDS hold
     int block = ctx->block;
     if (block == 0) {
         if (scheduled && ctx->persist)  // + 2080 B of LDS per wave: two 12-wave workgroups per CU up to a 55 KB scene image
