@@ -55,7 +55,8 @@ struct crt_context {
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
     int top_pairs_max = 1024;  // CRT_TOP_PAIRS
-    int persist = 1, unit_samples = 0;  // persistent waves; samples per unit (0: chosen per launch)
+    int persist = 1, unit_samples = 0;  // persistent waves; samples per coarse unit (0: chosen per launch)
+    int fine_samples = 0, fine_pct = 30;  // samples per fine unit (0: a quarter of the coarse ones), share of the samples cut into fine units
     int num_cus = 256;
 };
 
@@ -111,9 +112,11 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_TOP_PAIRS")) { int v = atoi(b); if (v >= 0 && v <= 2048) ctx->top_pairs_max = v; }
     if (const char* b = getenv("CRT_TAIL_PASS")) ctx->tail_pass = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
+    if (const char* b = getenv("CRT_UNIT_FINE")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->fine_samples = v; }
+    if (const char* b = getenv("CRT_UNIT_FINE_PCT")) { int v = atoi(b); if (v >= 0 && v <= 100) ctx->fine_pct = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 24 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
         false) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
@@ -359,7 +362,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     int grid;
     if (scheduled && ctx->persist) {
         // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
-        // wave pulling (tile, sample chunk) units; units sized for about 64 per wave, 4..64 samples each
+        // wave pulling (tile, sample chunk) units; coarse units sized for about 16 per wave, 8..32 samples each
         lds += size_t(nw) * 260 * 8;  // per wave: one tile of accumulators, its unit state, 32 block requests
         int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
         const int by_waves = 24 / nw;  // 6 waves per SIMD at the kernel's 75 VGPRs
@@ -367,13 +370,22 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         if (per_cu < 1) per_cu = 1;
         const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * nw;
         int us = ctx->unit_samples;
-        if (us == 0) { us = int(int64_t(ns_) * tiles / (64 * resident_waves)); us = us < 4 ? 4 : (us > 64 ? 64 : us); }
+        if (us == 0) { us = int(int64_t(ns_) * tiles / (16 * resident_waves)); us = us < 8 ? 8 : (us > 32 ? 32 : us); }
         a.persist = 1;
         a.top_pairs = top_pairs;
         a.tail_pass = ctx->tail_pass;
+        // the last fine_pct % of the samples go out in smaller units, after all the coarse ones
+        int fs = ctx->fine_samples;
+        if (fs == 0) fs = us / 4 < 2 ? 2 : us / 4;
+        if (ctx->fine_pct == 0 || fs >= us) fs = us;  // one unit size: the fine round only takes the remainder
+        const int ns_fine = fs < us ? int(int64_t(ns_) * ctx->fine_pct / 100) : 0;
         a.unit_samples = us;
-        a.unit_chunks = (ns_ + us - 1) / us;
-        const int64_t units = tiles * a.unit_chunks;
+        a.unit_chunks = (ns_ - ns_fine) / us;
+        a.ns_coarse = a.unit_chunks * us;
+        a.n_coarse = int(tiles * a.unit_chunks);
+        a.fine_samples = fs;
+        a.fine_chunks = (ns_ - a.ns_coarse + fs - 1) / fs;
+        const int64_t units = tiles * (int64_t(a.unit_chunks) + a.fine_chunks);
         if (units > (1ll << 31) - 1) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^31-1 work units (split the sample range)");
         a.n_units = int(units);
         const int64_t wgs = (units + nw - 1) / nw;
@@ -383,7 +395,7 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
         if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     }
-    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 24 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
     CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
@@ -439,7 +451,7 @@ int crt_debug_counters(crt_context* ctx, uint64_t* out16) {
     if (!ctx || !out16) return CRT_ERR_INVALID_ARGUMENT;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
-    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

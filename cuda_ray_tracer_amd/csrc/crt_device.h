@@ -58,9 +58,17 @@ struct crt_render_args {
     int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
     int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
     int persist;             // 1: persistent waves pulling (tile, sample chunk) units from counters[15]
-    int unit_samples;        // persistent: samples per unit (1..64)
-    int unit_chunks;         // persistent: units per tile = ceil(ns / unit_samples)
-    int n_units;             // persistent: tiles_x * tiles_y * unit_chunks
+    // persistent: a tile's ns samples are cut into unit_chunks chunks of unit_samples (covering
+    // samples [0, ns_coarse)) followed by fine_chunks chunks of fine_samples (the rest); all coarse
+    // units come first (tile-major), then all fine units: small units at the end of the launch
+    // keep its tail short, large ones before that keep the flush traffic low
+    int unit_samples;        // samples per coarse unit (1..64)
+    int unit_chunks;         // coarse units per tile
+    int ns_coarse;           // samples covered by the coarse units (unit_chunks * unit_samples, <= ns)
+    int n_coarse;            // tiles_x * tiles_y * unit_chunks
+    int fine_samples;        // samples per fine unit (1..64)
+    int fine_chunks;         // fine units per tile = ceil((ns - ns_coarse) / fine_samples)
+    int n_units;             // n_coarse + tiles_x * tiles_y * fine_chunks
     int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major

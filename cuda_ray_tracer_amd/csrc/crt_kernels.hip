@@ -425,15 +425,24 @@ __device__ __forceinline__ void unit_next(const crt_render_args& a, unsigned lon
     if (u >= (uint32_t)a.n_units) {
         // no unit left: the paths still in flight belong to a flushed tile, like after any switch
         ust[U_FLAGS] = 2u; ust[U_NITEMS] = 0u;
+        if ((a.census & 2) && lane == __builtin_ctzll(m_act)) {  // timeline census: when this wave found the queue empty
+            const unsigned long long t = wall_clock64();
+            atomicAdd(&a.counters[22], t); atomicMax(&a.counters[23], t);
+        }
         ust[U_EPOCH] = uniform(ust[U_EPOCH]) + 1u;
     } else {
-        const uint32_t tile = u / (uint32_t)a.unit_chunks, chunk = u - tile * (uint32_t)a.unit_chunks;
+        // coarse units first, then the fine ones (crt_device.h)
+        const bool fine = u >= (uint32_t)a.n_coarse;
+        const uint32_t v = fine ? u - (uint32_t)a.n_coarse : u;
+        const uint32_t chunks = (uint32_t)(fine ? a.fine_chunks : a.unit_chunks);
+        const uint32_t size = (uint32_t)(fine ? a.fine_samples : a.unit_samples);
+        const uint32_t tile = v / chunks, chunk = v - tile * chunks;
         const uint32_t ty = tile / (uint32_t)a.tiles_x, tx = tile - ty * (uint32_t)a.tiles_x;
-        const uint32_t first = chunk * (uint32_t)a.unit_samples;
-        const uint32_t left = (uint32_t)a.ns - first;
+        const uint32_t first = (fine ? (uint32_t)a.ns_coarse : 0u) + chunk * size;
+        const uint32_t left = (uint32_t)a.ns - first;  // coarse chunks are all full (ns_coarse <= ns)
         ust[U_OX] = tx * 8u; ust[U_OY] = ty * 8u;
         ust[U_SBASE] = (uint32_t)a.s0 + first;
-        ust[U_NITEMS] = 64u * (left < (uint32_t)a.unit_samples ? left : (uint32_t)a.unit_samples);
+        ust[U_NITEMS] = 64u * (left < size ? left : size);
         ust[U_EPOCH] = uniform(ust[U_EPOCH]) + 1u;
         ust[U_FLAGS] = 1u;
     }
@@ -483,6 +492,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     const bool timing = COUNT && (a.census & 2);
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};  // scheduler, walking, spheres, shade part 1, block loop, shade part 3
     long long t_mark = timing ? (long long)__builtin_readcyclecounter() : 0;
+    if (timing && lane == 0) {  // timeline census (100 MHz wall clock): start, queue-empty and exit time of each wave
+        const unsigned long long t = wall_clock64();
+        atomicMax(&a.counters[24], ~t); atomicAdd(&a.counters[27], t); atomicAdd(&a.counters[28], 1ull);
+    }
 #define CRT_LAP(i) do { if (timing) { const long long t_ = (long long)__builtin_readcyclecounter(); tc[i] += (unsigned long long)(t_ - t_mark); t_mark = t_; } } while (0)
 
     for (;;) {
@@ -877,8 +890,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       }
     }
     if (PERSIST && (uniform(ust[U_FLAGS]) & 1u)) unit_flush(a, pool.acc, ust, lane);
-    if (timing && lane == 0)
+    if (timing && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&a.counters[16 + i], tc[i]);
+        const unsigned long long t = wall_clock64();
+        atomicAdd(&a.counters[25], t); atomicMax(&a.counters[26], t);
+    }
 #undef CRT_LAP
 }
 

@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT")
 
 
 def make(variant, args):
@@ -71,7 +71,7 @@ def main():
             buf.zero_()
             r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
             st = r.stats()
-            c = (C.c_uint64 * 24)()
+            c = (C.c_uint64 * 32)()
             crt.lib().crt_debug_counters(r._ctx, c)
             c = list(c)
             names = ["RUN", "LEAF", "SHADE"]
@@ -83,11 +83,16 @@ def main():
             buf.zero_()
             r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
             st3 = r.stats()
-            t = (C.c_uint64 * 24)()
+            t = (C.c_uint64 * 32)()
             crt.lib().crt_debug_counters(r._ctx, t)
             tot = max(1, sum(t[16:22]))
             msg += f" cycles (kernel {st3.kernel_seconds * 1e3:.1f} ms): " + " ".join(
                 f"{nm} {t[16 + j] / tot * 100:.1f}%" for j, nm in enumerate(["sched", "walk", "sphere", "shade1", "blocks", "shade3"]))
+            if t[28]:
+                nwv, t0 = t[28], (~t[24]) & (2**64 - 1)
+                rel = lambda total: ((total - nwv * t0) % 2**64) / nwv / 100.0  # mean, microseconds after the first wave's start
+                msg += (f" timeline us after first start: {nwv} waves, start mean {rel(t[27]):.0f}; queue empty mean {rel(t[22]):.0f} last {(t[23] - t0) / 100.0:.0f};"
+                        f" exit mean {rel(t[25]):.0f} last {(t[26] - t0) / 100.0:.0f}")
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
     for i, v in enumerate(args.variants):
