@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2 = BASELINE configs[1] (the metric's config, default); c4 = configs[3], the synthetic "
                          "1M-sphere HBM stress (1920x1080, 64 spp) -- a DESIGN.md measurement, not the driver's line")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create the RCCL process group and issue every collective of the "
+                         "N > 1 path (one-GPU rehearsal, tests/test_gpu_rccl.py)")
     args = ap.parse_args()
     half, ground, cam_kw = 11, 1000.0, {}
     if args.config == "c4":  # the same generator on a 1000x1000 grid, camera pulled back 40x
@@ -89,8 +92,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world_size > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     # ---- set-up (also timed once as part of time-to-image) ----------------------------------
     t_setup0 = time.perf_counter()
@@ -118,12 +124,12 @@ def main():
         r.render_accumulate(crt.CRT_WORLD_BVH, first, count, args.depth, buf.data_ptr(), stream)
 
     def step():  # zero, trace this rank's samples, RCCL reduce(SUM) to rank 0, resolve to fp32 there
-        render_split(trace_range, sums, args.spp, world_size, rank)
+        render_split(trace_range, sums, args.spp, world_size, rank, always_reduce=use_dist)
         if rank == 0:
             r.resolve(sums.data_ptr(), args.spp, frame.data_ptr(), stream)
 
     def sync():
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +141,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -148,7 +154,7 @@ def main():
         kernel_s = r.kernel_times(min(args.steps, 64))
 
     t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device=dev)
-    if world_size > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -227,7 +233,7 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     r.close()
-    if world_size > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -21,14 +21,16 @@ def resolve(sums, spp):
     return (sums.to(torch.float64) * (2.0 ** -40 / spp)).to(torch.float32)
 
 
-def render_split(trace_range, sums, spp, world_size, rank):
+def render_split(trace_range, sums, spp, world_size, rank, always_reduce=False):
     """One image: zero `sums`, trace this rank's samples into it with `trace_range(lo, n, sums)`,
     reduce to rank 0.  `sums` is a (H, W, 3) int64 tensor on the rank's device; after the call rank
-    0 holds the sums of all `spp` samples (resolve them with crt_resolve / resolve())."""
+    0 holds the sums of all `spp` samples (resolve them with crt_resolve / resolve()).
+    `always_reduce`: issue the collective in a one-rank group too (the one-GPU rehearsal of the
+    N > 1 path: tests/test_gpu_rccl.py)."""
     lo, hi = sample_range(spp, world_size, rank)
     sums.zero_()
     if hi > lo:
         trace_range(lo, hi - lo, sums)
-    if world_size > 1:
+    if world_size > 1 or always_reduce:
         dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
     return sums

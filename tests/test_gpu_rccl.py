@@ -1,0 +1,31 @@
+"""One-GPU rehearsal of the N > 1 path on the real backend: bench.py with --force-dist creates the
+RCCL ("nccl") process group with one rank and issues every collective of the multi-GPU step
+(reduce(SUM) of the int64 sums to rank 0, barrier, the MAX / SUM all-reduces of the timing), so the
+API use, dtypes and stream ordering of that path are exercised on an MI355X; the N-rank arithmetic
+itself is covered by the gloo tests (test_multi_rank_gloo.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_step_through_rccl_group_of_one():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29600 + os.getpid() % 300))
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+              "--width", "160", "--spp", "8", "--cpu-seconds", "0"]
+    plain = subprocess.run(common, env=env, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = subprocess.run(common + ["--force-dist"], env=env, capture_output=True, text=True, timeout=300)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
+    # same rays, and the frame that went through the RCCL reduce is the frame rendered without it
+    assert a["rays_per_step"] == b["rays_per_step"] > 0
+    assert a["image_mean"] == b["image_mean"]
+    assert b["n_gpus"] == 1 and b["value"] > 0
