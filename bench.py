@@ -221,13 +221,16 @@ def main():
             out["config"]["workload"] = (f"synthetic {scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
                                          f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
             hbm_gbs = (roofline["traffic"] / kavg / 1e9) if roofline["traffic"] else None
-            roofline.update({"kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=512, SCHED=2 (persistent waves)>",
-                             "hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+            roofline.update({"hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
                              "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
                                      "256 MB Infinity Cache: measured HBM traffic (PMC) is ~3% of the algorithmic bytes "
                                      "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
-                                     "instance is bound by cache/memory LATENCY (PMC: 67% of wave cycles waiting, L1 hit "
-                                     "79%, L2 hit 90%), not by HBM bandwidth; achieved/peak are the fp32 figures as for C2"})
+                                     "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
+                                     "79%, L2 hit 90%; I x rays / time = record_fetch_Gs against the 250-290 G dependent "
+                                     "64-byte record reads/s that tools/ubench/gather_quad.hip measures chip-wide from L1/L2), "
+                                     "not by HBM bandwidth; achieved/peak are the fp32 figures as for C2",
+                             "kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=768, SCHED=2 (persistent waves)>",
+                             "record_fetch_Gs": I * cst.rays / kavg / 1e9, "record_rate_limit_Gs": [250, 290]})
         if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(args, args.seed)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
