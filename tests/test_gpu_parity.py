@@ -284,11 +284,12 @@ def test_degenerate_ray_directions(crt, orc, rnd, small, vfov, env):
         r.close()
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(int(os.environ.get("CRT_FUZZ_CASES", "12"))))
 def test_fuzz_scene_camera_depth(crt, orc, case):
     """Seeded random configurations: scene size (LDS image or HBM path), camera inside / outside the
     scene, field of view, defocus, ragged frame sizes, sample offset, depth 1..50 -- frame, ray count
-    and traversal counters bit for bit against the oracle."""
+    and traversal counters bit for bit against the oracle, from the production kernel and from its
+    counting variant.  CRT_FUZZ_CASES=N widens the campaign (DESIGN.md records the last long run)."""
     rng = np.random.default_rng(1000 + case)
     half = int(rng.choice([1, 3, 6, 11, 14, 20]))
     sc, osc = crt.scene_random(100 + case, half), orc.scene_random(100 + case, half)
@@ -302,10 +303,14 @@ def test_fuzz_scene_camera_depth(crt, orc, case):
               lookat=tuple(float(x) for x in rng.uniform([-3, 0, -3], [3, 1, 3])))
     cam, ocam = crt.camera(W, spp, **kw), orc.camera(W, spp, **kw)
     r = _renderer(crt, sc, cam, 77 + case)
+    fb0, st0 = r.render(crt.CRT_WORLD_BVH, spp, s0, depth)
     r.set_count_stats(True)
     fb, st = r.render(crt.CRT_WORLD_BVH, spp, s0, depth)
     sums, ost = orc.render(osc, ocam, 77 + case, s0, spp, depth, onodes, nthreads=8)
-    assert _bits_equal(fb, orc.resolve(sums, spp)), (case, half, W, spp, s0, depth, kw)
+    want = orc.resolve(sums, spp)
+    assert _bits_equal(fb0, want), (case, half, W, spp, s0, depth, kw)
+    assert _bits_equal(fb, want), (case, half, W, spp, s0, depth, kw)
+    assert st0.rays == ost[0]
     assert [st.rays, st.pair_visits, st.sphere_tests, st.samples] == ost
     r.close()
 
