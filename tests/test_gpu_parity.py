@@ -68,7 +68,11 @@ def _tie_scene(crt, n, seed):
     return crt.Scene(center, motion, radius, np.zeros(n, np.int32), [0], [[0.5, 0.5, 0.5]], [0.0])
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 9, 31, 33, 100, 1000, 4097, 14000])
+_BVH_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 31, 33, 100, 1000, 4097, 14000]
+_BVH_SIZES += [int(x) for x in np.random.default_rng(7).integers(1, 20000, int(os.environ.get("CRT_BVH_FUZZ_SIZES", "0")))]
+
+
+@pytest.mark.parametrize("n", _BVH_SIZES)
 def test_gpu_bvh_builder_matches_host_builder(crt, orc, n):
     """crt_build_bvh (GPU: one stable radix sort per tree level, crt_bvh.hip) against crt_bvh_build_host (the
     reference's recursion replayed on the host), which tests/test_host_parity.py holds to the oracle: the node
