@@ -26,6 +26,26 @@ def test_oracle_reproduces_golden(orc):
     assert orc.scene_random(18, 11).n == int(g["random_n"])
 
 
+def test_oracle_reproduces_golden_paths_and_c1_frame(orc):
+    """individual paths at the C1 / C2 geometry and the full C1 frame's SHA-256."""
+    import hashlib
+    g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+    for name, sc, width, spp, depth in (("c1", orc.scene_small(), 400, 10, 10), ("c2", orc.scene_random(18, 11), 1200, 500, 50)):
+        nodes, _ = orc.bvh_build(sc, 17)
+        cam = orc.camera(width, spp)
+        pps = g[name + "_paths_pixel_sample"]
+        for world, wn in ((None, "list"), (nodes, "bvh")):
+            for i in range(0, len(pps), 4):  # every fourth vector keeps the CPU suite quick
+                ray7, rgb, seg = orc.trace_sample(sc, cam, 1, int(pps[i, 0]), int(pps[i, 1]), int(pps[i, 2]), depth, world)
+                assert np.array_equal(ray7.view(np.uint32), g[f"{name}_paths_{wn}_ray"][i].view(np.uint32))
+                assert np.array_equal(rgb.view(np.uint32), g[f"{name}_paths_{wn}_rgb"][i].view(np.uint32))
+                assert seg == int(g[f"{name}_paths_{wn}_segments"][i])
+            if name == "c1":
+                sums, st = orc.render(sc, cam, 1, 0, 10, 10, world, nthreads=8)
+                assert hashlib.sha256(orc.resolve(sums, 10).tobytes()).digest() == bytes(g[f"c1_frame_{wn}_sha256"])
+                assert st[0] == int(g[f"c1_frame_{wn}_rays"])
+
+
 def test_product_host_bvh_matches_golden(crt):
     g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
     for name, sc in (("small", crt.scene_small()), ("random", crt.scene_random(18, 11))):

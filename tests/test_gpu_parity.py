@@ -148,6 +148,26 @@ def test_golden_fixture(crt):
         r.close()
 
 
+def test_golden_paths_and_c1_frame(crt):
+    """Committed vectors of SURVEY 8c (iv) and (v): 256 individual (pixel, sample) paths at the C1 and C2
+    geometry (primary ray, radiance, segment count; list and BVH) and the SHA-256 of the full C1 frame."""
+    import hashlib
+    g = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+    for name, sc, width, spp, depth in (("c1", crt.scene_small(), 400, 10, 10), ("c2", crt.scene_random(18, 11), 1200, 500, 50)):
+        r = _renderer(crt, sc, crt.camera(width, spp), 1)
+        px, py, smp = g[name + "_paths_pixel_sample"].T
+        for world, wn in ((crt.CRT_WORLD_LIST, "list"), (crt.CRT_WORLD_BVH, "bvh")):
+            ray7, rgb, seg = r.trace_samples(world, px, py, smp, depth)
+            assert _bits_equal(ray7, g[f"{name}_paths_{wn}_ray"])
+            assert _bits_equal(rgb, g[f"{name}_paths_{wn}_rgb"])
+            assert np.array_equal(seg, g[f"{name}_paths_{wn}_segments"])
+            if name == "c1":
+                fb, st = r.render(world, 10, 0, 10)
+                assert hashlib.sha256(np.ascontiguousarray(fb, np.float32).tobytes()).digest() == bytes(g[f"c1_frame_{wn}_sha256"])
+                assert st.rays == int(g[f"c1_frame_{wn}_rays"])
+        r.close()
+
+
 @pytest.mark.parametrize("env", [dict(), dict(CRT_SCHED=0), dict(CRT_PERSIST=0, CRT_TILES=1), dict(CRT_PERSIST=0, CRT_TILES=4),
                                  dict(CRT_PERSIST=0, CRT_TILES=16), dict(CRT_PERSIST=0, CRT_BLOCK=256), dict(CRT_PERSIST=0, CRT_LDS_LIMIT=0),
                                  dict(CRT_UNIT_SAMPLES=1), dict(CRT_UNIT_SAMPLES=5), dict(CRT_UNIT_SAMPLES=64), dict(CRT_UNIT_FINE_PCT=0), dict(CRT_UNIT_SAMPLES=3, CRT_UNIT_FINE=1, CRT_UNIT_FINE_PCT=50),
