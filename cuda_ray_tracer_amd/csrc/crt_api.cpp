@@ -192,6 +192,7 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
     ctx->nodes.clear(); ctx->num_leaves = 0;
+    ctx->n = ctx->m = 0;  // no scene until the new one is completely on the device
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_spheres, sph.size() * sizeof(float)));
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_mats, mats.size() * sizeof(float)));
     CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_spheres, sph.data(), sph.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -213,7 +214,7 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
     const int L = 1 << depth;
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
-    ctx->nodes.clear();
+    ctx->nodes.clear(); ctx->num_leaves = 0;
     if (!ctx->bvh_host) {
         // GPU builder (crt_bvh.hip): boxes and the axis table come from the host code both builders share
         const size_t n = size_t(ctx->n);

@@ -161,7 +161,9 @@ int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offs
  * interleaved, in 2^-40 fixed point: each sample's radiance component r contributes
  * (int64)(min(r, 4096) * 2^40).  Integer sums are associative, so the buffer -- and the image --
  * is bit-identical however the samples are split over calls, workgroups or GPUs.  This is what
- * multi-GPU sample splitting and progressive accumulation call. */
+ * multi-GPU sample splitting and progressive accumulation call.
+ * Launches of ONE context share its work-queue counter and statistics: issue them on one stream
+ * (or otherwise ordered); launches that overlap on the GPU need a context each. */
 int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
                           int32_t max_depth, int64_t* d_sums, void* stream);
 
