@@ -190,11 +190,12 @@ def main():
         }
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is
         # the rocprofv3 FETCH_SIZE + WRITE_SIZE measurement of the same launch committed under profiles/
+        # (FETCH_SIZE doubled: on gfx950 it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md 'HBM')
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[args.config]
             if W == (1200 if args.config == "c2" else 1920) and world_size == 1:
                 roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
-                roofline["traffic_source"] = pmc.get("file", "profiles/r01_d_pmc_summary.txt")
+                roofline["traffic_source"] = pmc.get("file", "profiles/r01_e_pmc_summary.txt")
         except (OSError, KeyError, ValueError):
             pass
         # time-to-image: set-up + one step + read-back of the finished frame
@@ -223,7 +224,7 @@ def main():
             hbm_gbs = (roofline["traffic"] / kavg / 1e9) if roofline["traffic"] else None
             roofline.update({"hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
                              "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
-                                     "256 MB Infinity Cache: measured HBM traffic (PMC) is ~3% of the algorithmic bytes "
+                                     "256 MB Infinity Cache: measured memory-side traffic (PMC, FETCH_SIZE doubled per the gfx950 correction) is <=6% of the algorithmic bytes "
                                      "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
                                      "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
                                      "79%, L2 hit 90%; I x rays / time = record_fetch_Gs against the 250-290 G dependent "
