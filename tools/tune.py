@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_DRAIN")
 
 
 def make(variant, args):
@@ -93,6 +93,7 @@ def main():
                 rel = lambda total: ((total - nwv * t0) % 2**64) / nwv / 100.0  # mean, microseconds after the first wave's start
                 msg += (f" timeline us after first start: {nwv} waves, start mean {rel(t[27]):.0f}; queue empty mean {rel(t[22]):.0f} last {(t[23] - t0) / 100.0:.0f};"
                         f" exit mean {rel(t[25]):.0f} last {(t[26] - t0) / 100.0:.0f}")
+            msg += f" drain pool: offered {c[29]} adopted {c[30]} reclaimed {c[31]}"
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
     for i, v in enumerate(args.variants):
