@@ -117,8 +117,8 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_UNIT_FINE")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->fine_samples = v; }
     if (const char* b = getenv("CRT_UNIT_FINE_PCT")) { int v = atoi(b); if (v >= 0 && v <= 100) ctx->fine_pct = v; }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->d_counters, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess ||
         false) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
@@ -456,6 +456,16 @@ int crt_debug_counters(crt_context* ctx, uint64_t* out16) {
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
     CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+// not part of the public header: (start, queue-empty, exit) wall-clock ticks (100 MHz) of the first 8192 waves of the
+// last phase-cycle census launch (crt_set_count_stats(ctx, 3)); tools/tune.py
+int crt_debug_timeline(crt_context* ctx, uint64_t* out, int32_t waves) {
+    if (!ctx || !out || waves < 1 || waves > 8192) return CRT_ERR_INVALID_ARGUMENT;
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    CRT_HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters + 32, size_t(waves) * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

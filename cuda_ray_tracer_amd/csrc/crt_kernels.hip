@@ -430,6 +430,8 @@ __device__ __forceinline__ void unit_next(const crt_render_args& a, unsigned lon
         if ((a.census & 2) && lane == __builtin_ctzll(m_act)) {  // timeline census: when this wave found the queue empty
             const unsigned long long t = wall_clock64();
             atomicAdd(&a.counters[22], t); atomicMax(&a.counters[23], t);
+            const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            if (wid < 8192u) a.counters[32 + 3 * wid + 1] = t;
         }
         ust[U_EPOCH] = uniform(ust[U_EPOCH]) + 1u;
     } else {
@@ -497,6 +499,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     if (timing && lane == 0) {  // timeline census (100 MHz wall clock): start, queue-empty and exit time of each wave
         const unsigned long long t = wall_clock64();
         atomicMax(&a.counters[24], ~t); atomicAdd(&a.counters[27], t); atomicAdd(&a.counters[28], 1ull);
+        const uint32_t wid = blockIdx.x * (uint32_t)pool.nw + (uint32_t)pool.wave;
+        if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid] = t;
     }
     // begin external_hit for a new segment of this lane's path
     auto begin_segment = [&]() {
@@ -995,6 +999,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         for (int i = 0; i < 6; ++i) atomicAdd(&a.counters[16 + i], tc[i]);
         const unsigned long long t = wall_clock64();
         atomicAdd(&a.counters[25], t); atomicMax(&a.counters[26], t);
+        const uint32_t wid = blockIdx.x * (uint32_t)pool.nw + (uint32_t)pool.wave;
+        if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid + 2] = t;
     }
 #undef CRT_LAP
 }

@@ -93,6 +93,14 @@ def main():
                 rel = lambda total: ((total - nwv * t0) % 2**64) / nwv / 100.0  # mean, microseconds after the first wave's start
                 msg += (f" timeline us after first start: {nwv} waves, start mean {rel(t[27]):.0f}; queue empty mean {rel(t[22]):.0f} last {(t[23] - t0) / 100.0:.0f};"
                         f" exit mean {rel(t[25]):.0f} last {(t[26] - t0) / 100.0:.0f}")
+                import numpy as np
+                nwv = min(int(nwv), 8192)
+                tl = (C.c_uint64 * (3 * nwv))()
+                crt.lib().crt_debug_timeline(r._ctx, tl, nwv)
+                tl = np.array(tl, dtype=np.uint64).reshape(nwv, 3).astype(np.int64)
+                base = tl[:, 0].min()
+                pct = lambda col: " ".join(f"{np.percentile((tl[:, col] - base) / 100.0, q):.0f}" for q in (0, 1, 10, 50, 90, 99, 100))
+                msg += f" percentiles 0/1/10/50/90/99/100 us: queue empty {pct(1)}; exit {pct(2)}; exit - queue empty {' '.join(f'{np.percentile((tl[:, 2] - tl[:, 1]) / 100.0, q):.0f}' for q in (0, 10, 50, 90, 99, 100))}"
             msg += f" drain pool: offered {c[29]} adopted {c[30]} reclaimed {c[31]}"
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
