@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_hip.so")
+LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(_HERE, "libcrt_hip.so")  # CRT_LIB_PATH: A/B of two builds (tools)
 
 # every symbol include/crt_hip.h declares
 EXPORTS = [
