@@ -87,5 +87,8 @@ def load(path=LIB_PATH):
     lib.crt_set_count_stats.argtypes = [vp, C.c_int32]
     lib.crt_trace_samples.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, ip, C.c_int32, fp, fp, ip]
     lib.crt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]  # internal, not in the header
-    lib.crt_debug_timeline.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]  # internal, not in the header
+    try:  # absent from older builds (CRT_LIB_PATH A/Bs)
+        lib.crt_debug_timeline.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]  # internal, not in the header
+    except AttributeError:
+        pass
     return lib

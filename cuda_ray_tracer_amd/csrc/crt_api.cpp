@@ -54,7 +54,6 @@ struct crt_context {
     size_t lds_limit = 126 * 1024;  // scene image that still leaves room for one 16-wave workgroup per CU (55 KB: two 12-wave ones)
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
-    int drain_t = 16;  // CRT_DRAIN: drain pool threshold (live lanes), 0 = off
     int top_pairs_max = 1024;  // CRT_TOP_PAIRS
     int persist = 1, unit_samples = 0;  // persistent waves; samples per coarse unit (0: chosen per launch)
     int fine_samples = 0, fine_pct = 30;  // samples per fine unit (0: a quarter of the coarse ones), share of the samples cut into fine units
@@ -111,7 +110,6 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_PERSIST")) ctx->persist = atoi(b) != 0;
     if (const char* b = getenv("CRT_BVH_HOST")) ctx->bvh_host = atoi(b) != 0;
     if (const char* b = getenv("CRT_TOP_PAIRS")) { int v = atoi(b); if (v >= 0 && v <= 2048) ctx->top_pairs_max = v; }
-    if (const char* b = getenv("CRT_DRAIN")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->drain_t = v; }
     if (const char* b = getenv("CRT_TAIL_PASS")) ctx->tail_pass = atoi(b) != 0;
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     if (const char* b = getenv("CRT_UNIT_FINE")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->fine_samples = v; }
@@ -377,7 +375,6 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         a.persist = 1;
         a.top_pairs = top_pairs;
         a.tail_pass = ctx->tail_pass;
-        a.drain_t = ctx->drain_t;
         // the last fine_pct % of the samples go out in smaller units, after all the coarse ones
         int fs = ctx->fine_samples;
         if (fs == 0) fs = us / 4 < 2 ? 2 : us / 4;

@@ -70,10 +70,9 @@ struct crt_render_args {
     int fine_chunks;         // fine units per tile = ceil((ns - ns_coarse) / fine_samples)
     int n_units;             // n_coarse + tiles_x * tiles_y * fine_chunks
     int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
-    int drain_t;             // persistent: a wave with <= drain_t live lanes after the queue ran dry offers its paths to the workgroup's lower waves (0: off)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
-    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit [16..21] phase cycles [22..28] timeline [29..31] drain pool: offered, adopted, reclaimed
+    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit [16..21] phase cycles [22..28] timeline census; [32 + 3 w ...] (start, queue empty, exit) of wave w < 8192
 };
 
 #endif

@@ -382,7 +382,6 @@ struct wg_pool {
     const int2* origin;       // LDS: pixel origin (x, y) of each of the T tiles; x < 0: tile outside the frame
     uint32_t total;           // 64 * T * ns
     int shift;                // log2(64 * T)
-    int wave, nw;             // PERSIST: this wave's index in the workgroup, waves per workgroup (drain pool)
 };
 
 // Persistent waves (PERSIST).  The frame is cut into units = (8x8 tile, chunk of `unit_samples`
@@ -395,8 +394,7 @@ struct wg_pool {
 // The wave's unit state lives in LDS next to its accumulators (8 dwords, wave-private, read and
 // written by all active lanes with identical values), not in registers: it is touched once per
 // shade phase, and the walking loop keeps its register budget.
-enum { U_NITEMS = 0, U_NEXT = 1, U_EPOCH = 2, U_FLAGS = 3, U_OX = 4, U_OY = 5, U_SBASE = 6, U_OPEN = 7 };  // U_FLAGS: 1 have, 2 drained, 4 no more offers
-enum { DRAIN_SLOTS = 24, DRAIN_WORDS = 16, WAVE_LDS_U64 = 260 };  // drain pool: 24 slots of 16 dwords = the wave's 192 accumulators
+enum { U_NITEMS = 0, U_NEXT = 1, U_EPOCH = 2, U_FLAGS = 3, U_OX = 4, U_OY = 5, U_SBASE = 6 };  // U_FLAGS: 1 have, 2 drained
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -499,34 +497,9 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     if (timing && lane == 0) {  // timeline census (100 MHz wall clock): start, queue-empty and exit time of each wave
         const unsigned long long t = wall_clock64();
         atomicMax(&a.counters[24], ~t); atomicAdd(&a.counters[27], t); atomicAdd(&a.counters[28], 1ull);
-        const uint32_t wid = blockIdx.x * (uint32_t)pool.nw + (uint32_t)pool.wave;
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // per-wave records: start, queue empty, exit
         if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid] = t;
     }
-    // begin external_hit for a new segment of this lane's path
-    auto begin_segment = [&]() {
-        best_t = __builtin_huge_valf(); best_obj = -1;
-        ray_a = len2(p.r.d);
-        k = 1u; pending = 1u;  // the root, below the sentinel
-        if (NL == 1u) {
-            // the root is the only leaf (k >= NL: sphere phase next): no box is tested
-        } else {
-            inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
-            exact = !finite3(inv);
-            if (IN_LDS) {
-                offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
-                offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
-                offz = (p.r.d.z < 0.0f ? 5u * NL : 4u * NL) << 4;
-            }
-        }
-    };
-    // Drain pool (PERSIST, a.drain_t > 0).  Once the unit queue is empty every wave runs its last <= 64
-    // paths out with fewer and fewer live lanes.  A wave down to <= drain_t live lanes OFFERS the
-    // paths that pass its shade phase (state at the start of a segment: 15 dwords) in the LDS area
-    // of its accumulators, which the drain no longer uses (paths of a flushed unit add to the frame
-    // directly); waves with a LOWER index in the workgroup and idle lanes take them over, so the
-    // workgroup's paths collect in few, fuller waves.  Nobody ever waits: a slot is claimed by
-    // compare-and-swap, by a lower wave or -- when the owner has nothing else left -- by the owner
-    // itself, which then stops offering.  Slot word 0: 0 free, 1 offered, 2 being read.
 #define CRT_LAP(i) do { if (timing) { const long long t_ = (long long)__builtin_readcyclecounter(); tc[i] += (unsigned long long)(t_ - t_mark); t_mark = t_; } } while (0)
 
     for (;;) {
@@ -647,17 +620,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             CRT_LAP(2);
         }
       }
-      bool reclaim = false;
-      if (phase < 0) {
-          // nothing left in this wave: once, take back what it offered and nobody adopted (one more pass
-          // through the shade phase below, with no lane shading), and stop offering
-          if (PERSIST && a.drain_t > 0 && uniform(ust[U_OPEN]) != 0u && !(uniform(ust[U_FLAGS]) & 8u)) {
-              ust[U_FLAGS] = uniform(ust[U_FLAGS]) | 12u;
-              reclaim = true;
-          } else {
-              break;
-          }
-      }
+      if (phase < 0) break;
       {
         {
             // The shade phase has three parts: (1) hit record / next work item, lanes in the shade
@@ -909,83 +872,19 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     p.sky_a = 0.5f * (unit(p.r.d).y + 1.0f);
                     p.depth = 0;
                 }
-                if (!finished && !fresh) begin_segment();
-            }
-            if (PERSIST && a.drain_t > 0 && (uniform(ust[U_FLAGS]) & 2u)) {
-                // drain pool, whole wave: offer (few live lanes, not the workgroup's first wave), then adopt.
-                // The loops only pair lanes with slots; the path state moves in one block after each.
-                const unsigned long long m_live = __ballot(!finished && !(fresh && k == 0u));
-                if (pool.wave > 0 && !(uniform(ust[U_FLAGS]) & 4u) && __popcll(m_live) <= a.drain_t) {
-                    unsigned long long m_off = __ballot(shading && !finished && !fresh);  // lanes that have just begun a segment
-                    if (m_off != 0ull) {
-                        uint32_t* slots = (uint32_t*)pool.acc;
-                        uint32_t st = 1u;
-                        if (lane < DRAIN_SLOTS) st = __hip_atomic_load(&slots[DRAIN_WORDS * lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        unsigned long long m_free = __ballot(st == 0u);
-                        int mine = -1;
-                        uint32_t n_off = 0u;
-                        while (m_off != 0ull && m_free != 0ull) {
-                            if (lane == __builtin_ctzll(m_off)) mine = __builtin_ctzll(m_free);
-                            m_off &= m_off - 1ull; m_free &= m_free - 1ull;
-                            ++n_off;
-                        }
-                        if (mine >= 0) {
-                            uint32_t* sl = slots + DRAIN_WORDS * mine;
-                            sl[1] = __float_as_uint(p.r.o.x); sl[2] = __float_as_uint(p.r.o.y); sl[3] = __float_as_uint(p.r.o.z);
-                            sl[4] = __float_as_uint(p.r.d.x); sl[5] = __float_as_uint(p.r.d.y); sl[6] = __float_as_uint(p.r.d.z);
-                            sl[7] = __float_as_uint(p.r.tm);
-                            sl[8] = __float_as_uint(p.thr.x); sl[9] = __float_as_uint(p.thr.y); sl[10] = __float_as_uint(p.thr.z);
-                            sl[11] = __float_as_uint(p.sky_a);
-                            sl[12] = (uint32_t)p.depth;
-                            sl[13] = rs.pixel; sl[14] = rs.sample; sl[15] = rs.event;
-                            __hip_atomic_store(&sl[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            finished = true; k = 0u;
-                        }
-                        if (lane == 0) atomicAdd(&ust[U_OPEN], n_off);
-                        if (COUNT && lane == 0) atomicAdd(&a.counters[29], (unsigned long long)n_off);
-                    }
-                }
-                unsigned long long m_idle = __ballot(finished);
-                if (m_idle != 0ull && (reclaim || pool.wave + 1 < pool.nw)) {
-                    // the victim: this wave itself (reclaim), else the first wave above it with open offers
-                    // (the waves' LDS areas lie WAVE_LDS_U64 * 8 bytes apart)
-                    int v = pool.wave;
-                    if (!reclaim) {
-                        uint32_t open = 0u;
-                        if (lane > pool.wave && lane < pool.nw)
-                            open = __hip_atomic_load((uint32_t*)((unsigned long long*)ust + WAVE_LDS_U64 * (lane - pool.wave)) + U_OPEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const unsigned long long m_cand = __ballot(open != 0u);
-                        v = m_cand != 0ull ? __builtin_ctzll(m_cand) : -1;
-                    }
-                    if (v >= 0) {
-                        uint32_t* vust = (uint32_t*)((unsigned long long*)ust + WAVE_LDS_U64 * (v - pool.wave));
-                        uint32_t* vslots = (uint32_t*)((unsigned long long*)vust - 192);
-                        uint32_t st = 0u;
-                        if (lane < DRAIN_SLOTS) st = __hip_atomic_load(&vslots[DRAIN_WORDS * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        unsigned long long m_open = __ballot(st == 1u);
-                        int mine = -1;
-                        while (m_idle != 0ull && m_open != 0ull) {
-                            if (lane == __builtin_ctzll(m_idle)) mine = __builtin_ctzll(m_open);
-                            m_idle &= m_idle - 1ull; m_open &= m_open - 1ull;
-                        }
-                        if (mine >= 0) {
-                            uint32_t* sl = vslots + DRAIN_WORDS * mine;
-                            uint32_t expect = 1u;
-                            if (__hip_atomic_compare_exchange_strong(&sl[0], &expect, 2u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                p.r.o = mk(__uint_as_float(sl[1]), __uint_as_float(sl[2]), __uint_as_float(sl[3]));
-                                p.r.d = mk(__uint_as_float(sl[4]), __uint_as_float(sl[5]), __uint_as_float(sl[6]));
-                                p.r.tm = __uint_as_float(sl[7]);
-                                p.thr = mk(__uint_as_float(sl[8]), __uint_as_float(sl[9]), __uint_as_float(sl[10]));
-                                p.sky_a = __uint_as_float(sl[11]);
-                                p.depth = (int)sl[12];
-                                rs.pixel = sl[13]; rs.sample = sl[14]; rs.event = sl[15];
-                                __hip_atomic_store(&sl[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                atomicSub(&vust[U_OPEN], 1u);
-                                if (COUNT) atomicAdd(&a.counters[reclaim ? 31 : 30], 1ull);
-                                slot = (uniform(ust[U_EPOCH]) + 1u) << 6;  // a foreign epoch: the radiance goes straight to the frame
-                                fresh = false; finished = false;
-                                begin_segment();
-                            }  // else: another wave was faster; this lane stays idle
+                if (!finished && !fresh) {  // begin external_hit for the new segment
+                    best_t = __builtin_huge_valf(); best_obj = -1;
+                    ray_a = len2(p.r.d);
+                    k = 1u; pending = 1u;  // the root, below the sentinel
+                    if (NL == 1u) {
+                        // the root is the only leaf (k >= NL: sphere phase next): no box is tested
+                    } else {
+                        inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
+                        exact = !finite3(inv);
+                        if (IN_LDS) {
+                            offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
+                            offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
+                            offz = (p.r.d.z < 0.0f ? 5u * NL : 4u * NL) << 4;
                         }
                     }
                 }
@@ -999,7 +898,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         for (int i = 0; i < 6; ++i) atomicAdd(&a.counters[16 + i], tc[i]);
         const unsigned long long t = wall_clock64();
         atomicAdd(&a.counters[25], t); atomicMax(&a.counters[26], t);
-        const uint32_t wid = blockIdx.x * (uint32_t)pool.nw + (uint32_t)pool.wave;
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid + 2] = t;
     }
 #undef CRT_LAP
@@ -1009,7 +908,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
 // SCHED: 0 = simple per-lane loop, 1 = wave-scheduled with a workgroup item pool, 2 = wave-scheduled
 // persistent waves
 template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, int SCHED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void render_kernel(const crt_render_args a) {
+__global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) {
     extern __shared__ float4 smem[];
     constexpr int NW = BLOCK / 64;
     const float4* pairs = (const float4*)a.pairs;
@@ -1059,11 +958,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
 
     if (WORLD == 1 && SCHED == 2) {
         // per wave: 192 accumulators + 8 dwords of unit state (all zero at the start) + 32 block requests
-        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + WAVE_LDS_U64 * wave;
-        for (int i = lane; i < WAVE_LDS_U64; i += 64) acc[i] = 0ull;
+        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + 260 * wave;
+        for (int i = lane; i < 260; i += 64) acc[i] = 0ull;
         __syncthreads();  // the scene image is complete; from here on the waves run independently
         wg_pool pool;
-        pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0; pool.wave = wave; pool.nw = NW;
+        pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0;
         trace_bvh_scheduled<IN_LDS, COUNT, true>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
     } else if (WORLD == 1 && SCHED == 1) {
         const int T = a.tiles_per_wg;  // power of two
@@ -1079,7 +978,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void
         if (threadIdx.x == 0) *counter = 0u;
         __syncthreads();
         wg_pool pool;
-        pool.acc = acc; pool.counter = counter; pool.origin = origin; pool.wave = wave; pool.nw = NW;
+        pool.acc = acc; pool.counter = counter; pool.origin = origin;
         pool.shift = 6 + (31 - __builtin_clz((unsigned)T));
         pool.total = (uint32_t)a.ns << pool.shift;
         trace_bvh_scheduled<IN_LDS, COUNT, false>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);

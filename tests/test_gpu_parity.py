@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KNOBS = ("CRT_BLOCK", "CRT_SCHED", "CRT_TILES", "CRT_LDS_LIMIT", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_RUN_SHIFT",
-         "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_DRAIN", "CRT_BVH_HOST", "CRT_TAIL_PASS", "CRT_TOP_PAIRS")
+         "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_BVH_HOST", "CRT_TAIL_PASS", "CRT_TOP_PAIRS")
 
 
 def _bits_equal(a, b):
@@ -171,8 +171,7 @@ def test_golden_paths_and_c1_frame(crt):
 @pytest.mark.parametrize("env", [dict(), dict(CRT_SCHED=0), dict(CRT_PERSIST=0, CRT_TILES=1), dict(CRT_PERSIST=0, CRT_TILES=4),
                                  dict(CRT_PERSIST=0, CRT_TILES=16), dict(CRT_PERSIST=0, CRT_BLOCK=256), dict(CRT_PERSIST=0, CRT_LDS_LIMIT=0),
                                  dict(CRT_UNIT_SAMPLES=1), dict(CRT_UNIT_SAMPLES=5), dict(CRT_UNIT_SAMPLES=64), dict(CRT_UNIT_FINE_PCT=0), dict(CRT_UNIT_SAMPLES=3, CRT_UNIT_FINE=1, CRT_UNIT_FINE_PCT=50),
-                                 dict(CRT_UNIT_SAMPLES=16, CRT_UNIT_FINE=5, CRT_UNIT_FINE_PCT=100), dict(CRT_TAIL_PASS=0), dict(CRT_DRAIN=0), dict(CRT_DRAIN=64),
-                                 dict(CRT_DRAIN=64, CRT_BLOCK=256), dict(CRT_DRAIN=5, CRT_BLOCK=1024), dict(CRT_DRAIN=64, CRT_LDS_LIMIT=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=64),
+                                 dict(CRT_UNIT_SAMPLES=16, CRT_UNIT_FINE=5, CRT_UNIT_FINE_PCT=100), dict(CRT_TAIL_PASS=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=64),
                                  dict(CRT_BLOCK=256), dict(CRT_BLOCK=1024), dict(CRT_LDS_LIMIT=0),
                                  dict(CRT_LEAF_NUM=1, CRT_SHADE_NUM=1, CRT_RUN_SHIFT=6),
                                  dict(CRT_LEAF_NUM=16, CRT_SHADE_NUM=16, CRT_RUN_SHIFT=0)])

@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_DRAIN")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT")
 
 
 def make(variant, args):
@@ -101,7 +101,6 @@ def main():
                 base = tl[:, 0].min()
                 pct = lambda col: " ".join(f"{np.percentile((tl[:, col] - base) / 100.0, q):.0f}" for q in (0, 1, 10, 50, 90, 99, 100))
                 msg += f" percentiles 0/1/10/50/90/99/100 us: queue empty {pct(1)}; exit {pct(2)}; exit - queue empty {' '.join(f'{np.percentile((tl[:, 2] - tl[:, 1]) / 100.0, q):.0f}' for q in (0, 10, 50, 90, 99, 100))}"
-            msg += f" drain pool: offered {c[29]} adopted {c[30]} reclaimed {c[31]}"
             print(f"# census {args.variants[i]!r}: kernel {st.kernel_seconds * 1e3:.2f} ms, I/ray {st.pair_visits / st.rays:.2f} S/ray {st.sphere_tests / st.rays:.2f}; {msg}")
             r.set_count_stats(False)
     for i, v in enumerate(args.variants):
