@@ -182,6 +182,9 @@ def main():
             "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
             "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
             "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
+            # the arithmetic contract (-ffp-contract=off: the reference's separately rounded multiplies and adds)
+            # rules out FMA, which is half of the 157.3 TFLOP/s: against the add/mul issue peak the fraction doubles
+            "peak_without_fma": VALU_FP32_PEAK_TFLOPS / 2, "frac_without_fma": achieved_tflops / (VALU_FP32_PEAK_TFLOPS / 2),
             "note": "not a dense contraction (no MFMA); the BVH (50 KB of sign-sorted box planes + leaf tags) is LDS-resident and the "
                     "15 KB of spheres stay in L1/L2 (HBM traffic = the frame only): the bound is fp32 VALU issue under wave64 "
                     "divergence; peak = 157.3 TFLOP/s fp32 vector (= the f32-input MFMA dense peak); flops_per_ray is the "
@@ -196,6 +199,8 @@ def main():
             if W == (1200 if args.config == "c2" else 1920) and world_size == 1:
                 roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
                 roofline["traffic_source"] = pmc.get("file", "profiles/r01_e_pmc_summary.txt")
+                if "valu" in pmc:  # PMC view of the same kernel: what the SIMDs actually issue
+                    roofline["pmc"] = pmc["valu"]
         except (OSError, KeyError, ValueError):
             pass
         # time-to-image: set-up + one step + read-back of the finished frame
