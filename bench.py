@@ -232,8 +232,10 @@ def main():
                                      "256 MB Infinity Cache: measured memory-side traffic (PMC, FETCH_SIZE doubled per the gfx950 correction) is <=6% of the algorithmic bytes "
                                      "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
                                      "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
-                                     "79%, L2 hit 90%; I x rays / time = record_fetch_Gs against the 250-290 G dependent "
-                                     "64-byte record reads/s that tools/ubench/gather_quad.hip measures chip-wide from L1/L2), "
+                                     "79%, L2 hit 90%, ~1.0 L1 access per clock per CU against the 1.2-1.5 that "
+                                     "tools/ubench/gather_quad.hip reaches with dependent 64-byte record reads and nothing else "
+                                     "to do = 250-290 G records/s chip-wide; record_fetch_Gs = I x rays / time counts the upper "
+                                     "ten levels too, which come from LDS), "
                                      "not by HBM bandwidth; achieved/peak are the fp32 figures as for C2",
                              "kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=768, SCHED=2 (persistent waves)>",
                              "record_fetch_Gs": I * cst.rays / kavg / 1e9, "record_rate_limit_Gs": [250, 290]})
