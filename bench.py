@@ -11,56 +11,27 @@ Total work per step is fixed, so scaling over N is "strong".
 Metric: Mrays/s, whole job; one ray = one closest-hit query of the bounce loop
 (render_with_cuda.h:41), counted on the device.
 
-  python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import cuda_ray_tracer_amd as crt  # noqa: E402
-from cuda_ray_tracer_amd.multi_gpu import render_split, sample_range  # noqa: E402
-
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= the f32 MFMA dense peak)
 HBM_PEAK_GBS = 8000.0
+L1_RECORD_RATE_PEAK_GS = 290.0  # tools/ubench/gather_quad.hip: dependent 64-byte record reads, chip-wide, L1-resident table
 
 
-def cpu_baseline(args, seed):
-    """The oracle (a scalar port of the reference loop) on this box's host cores: bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as orc
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    threads = max(1, min(threads, os.cpu_count() or 1))
-    sc = orc.scene_random(args.scene_seed, 11)
-    nodes, _ = orc.bvh_build(sc, 17)
-    cam = orc.camera(args.width, args.spp)
-    t0 = time.perf_counter()
-    _, st = orc.render(sc, cam, seed, 0, 1, args.depth, nodes, nthreads=threads)
-    t1 = time.perf_counter() - t0
-    spp = int(max(1, min(128, args.cpu_seconds / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    _, st = orc.render(sc, cam, seed, 1, spp, args.depth, nodes, nthreads=threads)
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, st1 = orc.render(sc, cam, seed, 0, 1, args.depth, nodes, region=(0, 300, args.width, 300 + 64), nthreads=1)
-    dt1 = time.perf_counter() - t0
-    return {"value": st[0] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"full {cam.image_width}x{cam.image_height} frame, {spp} of {args.spp} spp, depth {args.depth}, "
-                      f"BVH world, {st[0]} rays in {dt:.2f} s on {threads} threads (oracle/rt_oracle.cpp, g++ -O2)",
-            "single_thread_mrays_s": st1[0] / dt1 / 1e6}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -70,90 +41,266 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scene-seed", type=int, default=18)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
-                    help="c2 = BASELINE configs[1] (the metric's config, default); c4 = configs[3], the synthetic "
-                         "1M-sphere HBM stress (1920x1080, 64 spp) -- a DESIGN.md measurement, not the driver's line")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="target CPU time of each cpu_baseline sample (0 = skip)")
+    ap.add_argument("--config", choices=["c1", "c2", "c4"], default="c2",
+                    help="c2 = BASELINE configs[1] (the metric's config, default); c1 = configs[0], the 5-sphere scene through "
+                         "the brute-force list world (400x225, 10 spp, depth 10); c4 = configs[3], the synthetic 1M-sphere "
+                         "HBM stress (1920x1080, 64 spp) -- c1/c4 are DESIGN.md measurements, not the driver's line")
+    ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
+                    help="N > 1: rank g traces samples [g spp/N, (g+1) spp/N) of every pixel (default, north_star), or "
+                         "all samples of the 8x8 tiles t = g mod N")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the RCCL process group and issue every collective of the "
                          "N > 1 path (one-GPU rehearsal, tests/test_gpu_rccl.py)")
-    args = ap.parse_args()
-    half, ground, cam_kw = 11, 1000.0, {}
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="control-flow rehearsal without a GPU (tests/test_bench_launcher.py): gloo ranks, CPU tensors and "
+                         "a stand-in tracer that adds 2^40 per sample; prints a line marked \"data\": \"rehearsal\"")
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 from a plain `python bench.py --gpus N`: start the ranks as fresh child processes ----------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_launch_command(n, argv, port):
+    """The child command of `python bench.py --gpus n ...` (argv = the parent's own arguments)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def launch_ranks(n, argv):
+    """Runs the N ranks as children and relays their output; the parent never touches the GPU (a process that
+    has initialised HIP must not exec or fork workers).  Returns the launcher's exit code (non-zero when any
+    rank failed)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.Popen(rank_launch_command(n, argv, free_port()), env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, seed):
+    """The oracle (a scalar port of the reference loop) on this box's host cores, on bounded samples of the
+    workload: once on the box's CPU share (OMP_NUM_THREADS, 16 per GPU on the pool), once on every hardware
+    thread the box reports, once on one thread.  `value` is the best of them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    host_cores = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = host_cores
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, host_cores)
+    share = max(1, min(share, host_cores))
+    all_threads = max(1, min(affinity, host_cores, 512))
+    sc = orc.scene_random(args.scene_seed, 11)
+    nodes, _ = orc.bvh_build(sc, 17)
+    cam = orc.camera(args.width, args.spp)
+
+    def sample(threads):
+        t0 = time.perf_counter()
+        orc.render(sc, cam, seed, 0, 1, args.depth, nodes, nthreads=threads)
+        t1 = time.perf_counter() - t0
+        spp = int(max(1, min(128, args.cpu_seconds / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        _, st = orc.render(sc, cam, seed, 1, spp, args.depth, nodes, nthreads=threads)
+        dt = time.perf_counter() - t0
+        return {"threads": threads, "mrays_s": st[0] / dt / 1e6, "spp": spp, "rays": st[0], "seconds": dt}
+
+    runs = [sample(share)]
+    if all_threads != share:
+        runs.append(sample(all_threads))
+    best = max(runs, key=lambda r: r["mrays_s"])
+    t0 = time.perf_counter()
+    _, st1 = orc.render(sc, cam, seed, 0, 1, args.depth, nodes, region=(0, 300, args.width, 300 + 64), nthreads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": best["mrays_s"], "unit": "Mrays/s", "cores": best["threads"], "kind": "port",
+            "sample": f"full {cam.image_width}x{cam.image_height} frame, {best['spp']} of {args.spp} spp, depth {args.depth}, "
+                      f"BVH world, {best['rays']} rays in {best['seconds']:.2f} s on {best['threads']} threads "
+                      f"(oracle/rt_oracle.cpp, g++ -O2)",
+            "host_cores": host_cores, "affinity_cores": affinity, "cpu_model": cpu_model(),
+            "runs": runs, "single_thread_mrays_s": st1[0] / dt1 / 1e6}
+
+
+# ---- one rank ---------------------------------------------------------------------------------------
+
+class GpuRank:
+    """This rank's GPU: context, scene, BVH, camera, buffers (torch is plumbing: device memory, stream, RCCL)."""
+
+    def __init__(self, args, local_rank, scene_kw, cam_kw):
+        import torch
+        import cuda_ray_tracer_amd as crt
+        self.torch, self.crt = torch, crt
+        n_dev = torch.cuda.device_count()  # does not initialise the GPU on this image
+        if local_rank >= n_dev:
+            raise SystemExit(f"bench.py: {args.gpus} devices requested, {n_dev} visible (rank {local_rank} has no GPU)")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.world = crt.CRT_WORLD_LIST if args.config == "c1" else crt.CRT_WORLD_BVH
+        t0 = time.perf_counter()
+        # first HIP work of the process: device discovery, queue creation, the runtime's own blit kernels -- HIP
+        # runtime start-up, not library code (tools/ctx_timing.py: crt_create itself takes 0.1 ms once HIP is up)
+        torch.zeros(1, device=self.dev)
+        torch.cuda.synchronize()
+        self.t_hip = time.perf_counter() - t0
+        self.r = crt.Renderer(local_rank, args.seed)
+        self.t_ctx = time.perf_counter() - t0 - self.t_hip   # crt_create: library state on an initialised runtime
+        self.scene = crt.scene_small() if args.config == "c1" else crt.scene_random(args.scene_seed, **scene_kw)
+        self.t_scene = time.perf_counter() - t0 - self.t_ctx - self.t_hip
+        self.r.upload_scene(self.scene)
+        t1 = time.perf_counter()
+        self.num_nodes = self.r.build_bvh(17)   # GPU builder (crt_bvh.hip); synchronous
+        self.t_bvh = time.perf_counter() - t1
+        self.cam = crt.camera(args.width, args.spp, **cam_kw)
+        self.r.set_camera(self.cam)
+        torch.cuda.synchronize()
+        self.t_setup = time.perf_counter() - t0
+        self.W, self.H = self.cam.image_width, self.cam.image_height
+        self.sums = torch.zeros(self.H, self.W, 3, dtype=torch.int64, device=self.dev)   # fixed-point (2^-40) RGB sums
+        self.frame = torch.empty(self.H, self.W, 3, dtype=torch.float32, device=self.dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.depth = args.depth
+        self.backend = "nccl"
+
+    def trace(self, first, count, tile_stride=1, tile_offset=0):
+        self.r.render_accumulate(self.world, first, count, self.depth, self.sums.data_ptr(), self.stream,
+                                 tile_stride=tile_stride, tile_offset=tile_offset)
+
+    def resolve(self, spp):
+        self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.stream)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        self.r.close()
+
+
+class RehearsalRank:
+    """No GPU: the same control flow on CPU tensors with a stand-in tracer (every sample adds 2^40 to every
+    component of its pixel, so a complete image resolves to exactly 1.0 whatever the split)."""
+
+    def __init__(self, args, local_rank, scene_kw, cam_kw):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cpu")
+        self.W, self.H = args.width, max(1, int(args.width / (16.0 / 9.0)))
+        self.sums = torch.zeros(self.H, self.W, 3, dtype=torch.int64)
+        self.frame = torch.empty(self.H, self.W, 3, dtype=torch.float32)
+        self.t_hip = self.t_ctx = self.t_scene = self.t_bvh = self.t_setup = 0.0
+        self.num_nodes, self.backend = 0, "gloo"
+        self.last = (0, 0)
+
+    def trace(self, first, count, tile_stride=1, tile_offset=0):
+        tiles_x = (self.W + 7) // 8
+        ty, tx = self.torch.meshgrid(self.torch.arange(self.H) // 8, self.torch.arange(self.W) // 8, indexing="ij")
+        mine = ((ty * tiles_x + tx) % tile_stride) == tile_offset
+        self.sums += (mine.to(self.torch.int64) * (count << 40))[:, :, None]
+        self.last = (int(mine.sum()) * count * 2, int(mine.sum()) * count)  # "rays" = 2 per sample
+
+    def resolve(self, spp):
+        self.frame.copy_((self.sums.to(self.torch.float64) * (2.0 ** -40 / spp)).to(self.torch.float32))
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: no torch.cuda / HIP call has happened in this process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cuda_ray_tracer_amd.multi_gpu import render_split, share_of_rank
+
+    scene_kw, cam_kw = dict(half=11, ground_radius=1000.0), {}
     if args.config == "c4":  # SURVEY.md 8(d) C4: the same generator on a 1000x1000 grid, camera pulled back 40x
-        half, ground = 500, 1.0e5
+        scene_kw = dict(half=500, ground_radius=1.0e5)
         cam_kw = dict(lookfrom=(520.0, 80.0, 120.0), focus_dist=540.0)
         if args.width == 1200 and args.spp == 500:
             args.width, args.spp = 1920, 64
+    if args.config == "c1" and args.width == 1200 and args.spp == 500 and args.depth == 50:
+        args.width, args.spp, args.depth = 400, 10, 10
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    g = (RehearsalRank if args.rehearse_cpu else GpuRank)(args, local_rank, scene_kw, cam_kw)
     use_dist = world_size > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        kw = {} if args.rehearse_cpu else {"device_id": g.dev}
+        dist.init_process_group(g.backend, rank=rank, world_size=world_size, **kw)
+    W, H = g.W, g.H
 
-    # ---- set-up (also timed once as part of time-to-image) ----------------------------------
-    t_setup0 = time.perf_counter()
-    r = crt.Renderer(local_rank, args.seed)
-    t_ctx = time.perf_counter() - t_setup0   # HIP context + code object load + library state
-    scene = crt.scene_random(args.scene_seed, half, ground)
-    t_scene = time.perf_counter() - t_setup0 - t_ctx
-    r.upload_scene(scene)
-    t_bvh0 = time.perf_counter()
-    num_nodes = r.build_bvh(17)   # GPU builder (crt_bvh.hip); synchronous
-    t_bvh = time.perf_counter() - t_bvh0
-    cam = crt.camera(args.width, args.spp, **cam_kw)
-    r.set_camera(cam)
-    torch.cuda.synchronize()
-    t_setup = time.perf_counter() - t_setup0
-    W, H = cam.image_width, cam.image_height
+    # this rank's share of one image: a sample range of every pixel, or every sample of every N-th tile
+    share = share_of_rank(args.spp, world_size, rank, args.split)
+    has_work = share["nsamples"] > 0
 
-    # sample split: rank g traces samples [lo, hi) of every pixel
-    lo, hi = sample_range(args.spp, world_size, rank)
-    sums = torch.zeros(H, W, 3, dtype=torch.int64, device=dev)   # fixed-point (2^-40) RGB sums
-    frame = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def trace_range(first, count, buf):
-        r.render_accumulate(crt.CRT_WORLD_BVH, first, count, args.depth, buf.data_ptr(), stream)
-
-    def step():  # zero, trace this rank's samples, RCCL reduce(SUM) to rank 0, resolve to fp32 there
-        render_split(trace_range, sums, args.spp, world_size, rank, always_reduce=use_dist)
+    def step():  # zero, trace this rank's share, RCCL reduce(SUM) to rank 0, resolve to fp32 there.  EVERY rank calls it.
+        render_split(g.trace, g.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split)
         if rank == 0:
-            r.resolve(sums.data_ptr(), args.spp, frame.data_ptr(), stream)
+            g.resolve(args.spp)
 
     def sync():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        g.sync()
 
     for _ in range(args.warmup):
         step()
     sync()
-    kernel_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    g.sync()
     if use_dist:
         dist.barrier()
-        torch.cuda.synchronize()
+        g.sync()
     elapsed = time.perf_counter() - t0
-    st = r.stats() if hi > lo else None  # last launch: rays of one step on this rank (identical every step)
-    rays_rank = float(st.rays) if st else 0.0
-    samples_rank = float(st.samples) if st else 0.0
-    # per-launch kernel time of the TIMED steps: HIP events the library records on the launch
-    # stream around every launch (it keeps the last 64)
-    if hi > lo:
-        kernel_s = r.kernel_times(min(args.steps, 64))
+    kernel_s = []
+    if args.rehearse_cpu:
+        rays_rank, samples_rank = (float(v) for v in g.last)
+    else:
+        st = g.r.stats() if has_work else None  # last launch: rays of one step on this rank (identical every step)
+        rays_rank = float(st.rays) if st else 0.0
+        samples_rank = float(st.samples) if st else 0.0
+        # per-launch kernel time of the TIMED steps: HIP events the library records on the launch
+        # stream around every launch (it keeps the last 64)
+        if has_work and args.steps > 0:
+            kernel_s = g.r.kernel_times(min(args.steps, 64))
 
-    t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device=g.dev)
     if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -161,91 +308,123 @@ def main():
         elapsed = float(tmax[0])
     rays_step, samples_step = float(t[1]), float(t[2])
 
+    # time-to-image: set-up + one step + read-back of the finished frame.  The step holds a collective, so
+    # every rank runs it; only rank 0 reads the frame back.
+    sync()
+    t1 = time.perf_counter()
+    step()
+    img = g.frame.cpu() if rank == 0 else None
+    g.sync()
+    t_image = g.t_setup + (time.perf_counter() - t1)
+    sync()
+
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
         value = rays_step * args.steps / elapsed / 1e6
-        # exact traversal work of this rank's share, from the counting kernel variant (untimed)
-        r.set_count_stats(True)
-        r.render_accumulate(crt.CRT_WORLD_BVH, lo, hi - lo, args.depth, sums.data_ptr(), stream)
-        cst = r.stats()
-        r.set_count_stats(False)
-        I = cst.pair_visits / cst.rays
-        S = cst.sphere_tests / cst.rays
-        flops_per_ray = 50.0 * I + 45.0 * S + 60.0
-        bytes_per_ray = 64.0 * I + 32.0 * S
-        kavg = float(np.mean(kernel_s))
-        achieved_tflops = flops_per_ray * cst.rays / kavg / 1e12
-        roofline = {
-            "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tflops / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-            "kernel": "render_kernel<WORLD=BVH, IN_LDS=1, COUNT=0, BLOCK=768, SCHED=2 (persistent waves)>", "kernel_ms": kavg * 1e3,
-            "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
-            "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
-            "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
-            # the arithmetic contract (-ffp-contract=off: the reference's separately rounded multiplies and adds)
-            # rules out FMA, which is half of the 157.3 TFLOP/s: against the add/mul issue peak the fraction doubles
-            "peak_without_fma": VALU_FP32_PEAK_TFLOPS / 2, "frac_without_fma": achieved_tflops / (VALU_FP32_PEAK_TFLOPS / 2),
-            "note": "not a dense contraction (no MFMA); the BVH (50 KB of sign-sorted box planes + leaf tags) is LDS-resident and the "
-                    "15 KB of spheres stay in L1/L2 (HBM traffic = the frame only): the bound is fp32 VALU issue under wave64 "
-                    "divergence; peak = 157.3 TFLOP/s fp32 vector (= the f32-input MFMA dense peak); flops_per_ray is the "
-                    "algorithmic count of SURVEY.md 8(d) (50 I + 45 S + 60), scene_fetch_GBs the algorithmic scene fetch rate "
-                    "(64 I + 32 S bytes per ray)",
-        }
-        # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is
-        # the rocprofv3 FETCH_SIZE + WRITE_SIZE measurement of the same launch committed under profiles/
-        # (FETCH_SIZE doubled: on gfx950 it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md 'HBM')
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[args.config]
-            if W == (1200 if args.config == "c2" else 1920) and world_size == 1:
-                roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
-                roofline["traffic_source"] = pmc.get("file", "profiles/r01_e_pmc_summary.txt")
-                if "valu" in pmc:  # PMC view of the same kernel: what the SIMDs actually issue
-                    roofline["pmc"] = pmc["valu"]
-        except (OSError, KeyError, ValueError):
-            pass
-        # time-to-image: set-up + one step + read-back of the finished frame
-        t1 = time.perf_counter()
-        step()
-        img = frame.cpu()
-        t_image = t_setup + (time.perf_counter() - t1)
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "rehearsal" if args.rehearse_cpu else "synthetic",
             "config": {"workload": f"RTOW random-spheres scene (helper.h:37-102, Philox scene seed {args.scene_seed}), "
                                    f"{W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH",
-                       "spheres": scene.n, "bvh_nodes": num_nodes, "width": W, "height": H, "spp": args.spp,
-                       "max_depth": args.depth, "parallelism": f"spp split x{world_size} + RCCL reduce(sum) to rank 0"},
+                       "width": W, "height": H, "spp": args.spp, "max_depth": args.depth,
+                       "parallelism": (f"spp split x{world_size}" if args.split == "samples" else f"8x8-tile split x{world_size}")
+                                      + " + RCCL reduce(sum) to rank 0"},
             "msamples_per_s": samples_step * args.steps / elapsed / 1e6,
-            "rays_per_step": rays_step, "segments_per_sample": rays_step / samples_step,
-            "time_to_image_ms": t_image * 1e3, "setup_ms": t_setup * 1e3,
-            "context_ms": t_ctx * 1e3, "scene_generation_ms": t_scene * 1e3, "bvh_build_ms": t_bvh * 1e3,
+            "rays_per_step": rays_step, "segments_per_sample": rays_step / max(samples_step, 1.0),
+            "time_to_image_ms": t_image * 1e3, "setup_ms": g.t_setup * 1e3,
+            "hip_runtime_init_ms": g.t_hip * 1e3, "context_ms": g.t_ctx * 1e3, "scene_generation_ms": g.t_scene * 1e3, "bvh_build_ms": g.t_bvh * 1e3,
             "image_mean": float(img.mean()),
-            "roofline": roofline,
         }
-        if args.config == "c4":
-            out["config"]["workload"] = (f"synthetic {scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
-                                         f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
-            hbm_gbs = (roofline["traffic"] / kavg / 1e9) if roofline["traffic"] else None
-            roofline.update({"hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
-                             "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
-                                     "256 MB Infinity Cache: measured memory-side traffic (PMC, FETCH_SIZE doubled per the gfx950 correction) is <=6% of the algorithmic bytes "
-                                     "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
-                                     "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
-                                     "79%, L2 hit 90%, ~1.0 L1 access per clock per CU against the 1.2-1.5 that "
-                                     "tools/ubench/gather_quad.hip reaches with dependent 64-byte record reads and nothing else "
-                                     "to do = 250-290 G records/s chip-wide; record_fetch_Gs = I x rays / time counts the upper "
-                                     "ten levels too, which come from LDS), "
-                                     "not by HBM bandwidth; achieved/peak are the fp32 figures as for C2",
-                             "kernel": "render_kernel<WORLD=BVH, IN_LDS=0, COUNT=0, BLOCK=768, SCHED=2 (persistent waves)>",
-                             "record_fetch_Gs": I * cst.rays / kavg / 1e9, "record_rate_limit_Gs": [250, 290]})
-        if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
-            out["cpu_baseline"] = cpu_baseline(args, args.seed)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if not args.rehearse_cpu:
+            gpu_report(args, g, out, share, kernel_s, world_size, np)
         print(json.dumps(out), flush=True)
-    r.close()
+    g.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def gpu_report(args, g, out, share, kernel_s, world_size, np):
+    """roofline + cpu_baseline of the line (rank 0 only; no collective in here)."""
+    crt, r = g.crt, g.r
+    W, H = g.W, g.H
+    build = crt.build_info()
+    out["arith"] = build["arith"]
+    out["library_build_id"] = build["build_id"]
+    out["config"].update({"spheres": g.scene.n, "bvh_nodes": g.num_nodes})
+    kernel = r.kernel_name()  # of the last timed-path launch (the time-to-image step)
+    # exact traversal work of this rank's share, from the counting kernel variant (untimed)
+    r.set_count_stats(True)
+    g.trace(share["first"], share["nsamples"], share["tile_stride"], share["tile_offset"])
+    cst = r.stats()
+    r.set_count_stats(False)
+    I = cst.pair_visits / cst.rays
+    S = cst.sphere_tests / cst.rays
+    flops_per_ray = 50.0 * I + 45.0 * S + 60.0  # SURVEY.md 8(d)
+    bytes_per_ray = 64.0 * I + 32.0 * S
+    kavg = float(np.mean(kernel_s))
+    achieved_tflops = flops_per_ray * cst.rays / kavg / 1e12
+    roofline = {
+        "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved_tflops / VALU_FP32_PEAK_TFLOPS, "traffic": None,
+        "kernel": kernel, "kernel_ms": kavg * 1e3,
+        "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
+        "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
+        "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
+        "note": "not a dense contraction (no MFMA); the BVH (50 KB of sign-sorted box planes + leaf tags) is LDS-resident and the "
+                "15 KB of spheres stay in L1/L2 (HBM traffic = the frame only): the bound is fp32 VALU issue under wave64 "
+                "divergence; peak = 157.3 TFLOP/s fp32 vector (= the f32-input MFMA dense peak); flops_per_ray is the "
+                "algorithmic count of SURVEY.md 8(d) (50 I + 45 S + 60), scene_fetch_GBs the algorithmic scene fetch rate "
+                "(64 I + 32 S bytes per ray)",
+    }
+    if build["arith"] == "exact":
+        # the exact arithmetic contract (-ffp-contract=off: the reference's separately rounded multiplies and adds)
+        # rules out FMA, which is half of the 157.3 TFLOP/s: against the add/mul issue peak the fraction doubles
+        roofline.update({"peak_without_fma": VALU_FP32_PEAK_TFLOPS / 2, "frac_without_fma": achieved_tflops / (VALU_FP32_PEAK_TFLOPS / 2)})
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the rocprofv3
+    # FETCH_SIZE + WRITE_SIZE measurement of the same launch committed under profiles/ (FETCH_SIZE doubled: on
+    # gfx950 it tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md 'HBM').  The file records the library
+    # build (hash of the kernel sources) and the kernel it was taken at: any other build or kernel reports null.
+    try:
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = pmc_all[args.config]
+        same = (pmc.get("build_id") == build["build_id"] and pmc.get("kernel") == kernel and pmc.get("width") == W
+                and pmc.get("spp") == args.spp and world_size == 1)
+        if same:
+            roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
+            roofline["traffic_source"] = f"committed profile {pmc.get('file')} (build {pmc.get('build_id')}, commit {pmc.get('commit')})"
+            if "valu" in pmc:  # PMC view of the same kernel: what the SIMDs actually issue
+                roofline["pmc"] = pmc["valu"]
+        else:
+            roofline["traffic_source"] = (f"null: profiles/pmc_traffic.json was taken at build {pmc.get('build_id')} / "
+                                          f"{pmc.get('kernel')}, this run is build {build['build_id']} / {kernel}")
+    except (OSError, KeyError, ValueError):
+        pass
+    out["roofline"] = roofline
+    if args.config == "c1":
+        out["config"]["workload"] = (f"RTOW small scene (helper.h:7-35, 5 spheres), {W}x{H}, {args.spp} spp, depth {args.depth}, "
+                                     "brute-force hittable_list world")
+    if args.config == "c4":
+        out["config"]["workload"] = (f"synthetic {g.scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
+                                     f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
+        hbm_gbs = (roofline["traffic"] / kavg / 1e9) if roofline["traffic"] else None
+        rec_gs = I * cst.rays / kavg / 1e9
+        roofline.update({"bound": "l1-request-rate", "achieved": rec_gs, "peak": L1_RECORD_RATE_PEAK_GS, "unit": "Grecords/s",
+                         "frac": rec_gs / L1_RECORD_RATE_PEAK_GS,
+                         "fp32_TFLOPs": achieved_tflops, "hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+                         "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
+                                 "256 MB Infinity Cache: measured memory-side traffic (PMC) is <=6% of the algorithmic bytes "
+                                 "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
+                                 "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
+                                 "79%, L2 hit 90%, ~1.0 L1 access per clock per CU); achieved = I x rays / time (child-pair "
+                                 "records per second, the upper ten levels come from LDS), peak = what "
+                                 "tools/ubench/gather_quad.hip reaches with dependent 64-byte record reads from an "
+                                 "L1-resident table and nothing else to do (250-290 G records/s chip-wide)",
+                         "record_fetch_Gs": rec_gs, "record_rate_limit_Gs": [250, 290]})
+    if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
+        out["cpu_baseline"] = cpu_baseline(args, args.seed)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
 
 
 if __name__ == "__main__":

@@ -10,11 +10,12 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CRT_DIELECTRIC, CRT_LAMBERTIAN, CRT_METAL, CRT_WORLD_BVH, CRT_WORLD_LIST, BvhNode, Camera,
-                    CameraParams, RenderStats)
+from ._capi import (CRT_ARITH_EXACT, CRT_ARITH_FAST, CRT_DIELECTRIC, CRT_LAMBERTIAN, CRT_METAL, CRT_SPLIT_SAMPLES,
+                    CRT_SPLIT_TILES, CRT_WORLD_BVH, CRT_WORLD_LIST, BvhNode, Camera, CameraParams, RenderStats)
 
 __all__ = ["lib", "Scene", "camera", "reference_camera", "scene_small", "scene_random", "bvh_build_host",
-           "write_ppm", "Renderer", "CRT_WORLD_LIST", "CRT_WORLD_BVH", "CrtError"]
+           "write_ppm", "Renderer", "Group", "build_info", "CRT_WORLD_LIST", "CRT_WORLD_BVH", "CRT_ARITH_EXACT",
+           "CRT_ARITH_FAST", "CRT_SPLIT_SAMPLES", "CRT_SPLIT_TILES", "CrtError"]
 
 _lib = None
 
@@ -128,19 +129,27 @@ def write_ppm(fb):
     return buf.raw[:need]
 
 
+def build_info():
+    """Hash of the kernel sources the loaded library was built from + the default arithmetic mode."""
+    import os
+    return {"build_id": lib().crt_build_id().decode(), "arith": "fast" if os.environ.get("CRT_ARITH") == "fast" else "exact"}
+
+
 class Renderer:
     """One crt_context: device + seed + scene + BVH + camera."""
 
-    def __init__(self, device=0, seed=1):
-        self._ctx = C.c_void_p()
-        _check(lib().crt_create(device, seed, C.byref(self._ctx)), "crt_create")
+    def __init__(self, device=0, seed=1, _ctx=None):
+        self._owned = _ctx is None
+        self._ctx = C.c_void_p() if _ctx is None else C.c_void_p(_ctx)
+        if _ctx is None:
+            _check(lib().crt_create(device, seed, C.byref(self._ctx)), "crt_create")
         self.cam = None
         self.scene = None
 
     def close(self):
-        if self._ctx:
+        if self._ctx and self._owned:
             lib().crt_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -168,9 +177,18 @@ class Renderer:
         _check(lib().crt_get_bvh_nodes(self._ctx, nodes, nn), "crt_get_bvh_nodes", self._ctx)
         return nodes
 
+    def upload_bvh_nodes(self, nodes):
+        _check(lib().crt_upload_bvh_nodes(self._ctx, nodes, len(nodes)), "crt_upload_bvh_nodes", self._ctx)
+
     def set_camera(self, cam):
         _check(lib().crt_set_camera(self._ctx, C.byref(cam)), "crt_set_camera", self._ctx)
         self.cam = cam
+
+    def set_arith(self, arith):
+        _check(lib().crt_set_arith(self._ctx, int(arith)), "crt_set_arith", self._ctx)
+
+    def kernel_name(self):
+        return lib().crt_last_kernel_name(self._ctx).decode()
 
     def set_count_stats(self, enable):
         _check(lib().crt_set_count_stats(self._ctx, int(enable)), "crt_set_count_stats", self._ctx)
@@ -182,9 +200,15 @@ class Renderer:
         _check(lib().crt_render(self._ctx, world, spp, sample_offset, max_depth, _fp(fb), C.byref(st)), "crt_render", self._ctx)
         return fb, st
 
-    def render_accumulate(self, world, sample_offset, nsamples, max_depth, d_sums_ptr, stream=None):
-        _check(lib().crt_render_accumulate(self._ctx, world, sample_offset, nsamples, max_depth, C.c_void_p(d_sums_ptr),
-                                           C.c_void_p(stream or 0)), "crt_render_accumulate", self._ctx)
+    def render_accumulate(self, world, sample_offset, nsamples, max_depth, d_sums_ptr, stream=None, tile_stride=1,
+                          tile_offset=0):
+        if tile_stride == 1 and tile_offset == 0:
+            _check(lib().crt_render_accumulate(self._ctx, world, sample_offset, nsamples, max_depth, C.c_void_p(d_sums_ptr),
+                                               C.c_void_p(stream or 0)), "crt_render_accumulate", self._ctx)
+        else:
+            _check(lib().crt_render_accumulate_tiles(self._ctx, world, sample_offset, nsamples, max_depth, tile_stride,
+                                                     tile_offset, C.c_void_p(d_sums_ptr), C.c_void_p(stream or 0)),
+                   "crt_render_accumulate_tiles", self._ctx)
 
     def resolve(self, d_sums_ptr, spp, d_fb_ptr, stream=None):
         _check(lib().crt_resolve(self._ctx, C.c_void_p(d_sums_ptr), spp, C.c_void_p(d_fb_ptr), C.c_void_p(stream or 0)),
@@ -211,3 +235,68 @@ class Renderer:
         _check(lib().crt_trace_samples(self._ctx, world, n, _ip(px), _ip(py), _ip(sample), max_depth, _fp(ray7), _fp(rgb),
                                        _ip(seg)), "crt_trace_samples", self._ctx)
         return ray7, rgb, seg
+
+
+class Group:
+    """crt_group: one context per entry of `devices`; one image cut over them (include/crt_hip.h)."""
+
+    def __init__(self, devices, seed=1):
+        self._grp = C.c_void_p()
+        devs = np.ascontiguousarray(devices, np.int32)
+        rc = lib().crt_group_create(_ip(devs), len(devs), seed, C.byref(self._grp))
+        if rc != 0:
+            raise CrtError(f"crt_group_create failed ({rc}): {lib().crt_group_last_error(None).decode()}")
+        self.cam = None
+        self.scene = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CrtError(f"{what} failed ({rc}): {lib().crt_group_last_error(self._grp).decode()}")
+
+    def close(self):
+        if self._grp:
+            lib().crt_group_destroy(self._grp)
+            self._grp = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().crt_group_size(self._grp)
+
+    def member(self, i):
+        """Borrowed Renderer view of member i (knobs, statistics); the group keeps ownership."""
+        ptr = lib().crt_group_member(self._grp, i)
+        if not ptr:
+            raise IndexError(i)
+        r = Renderer(_ctx=ptr)
+        r.cam, r.scene = self.cam, self.scene
+        return r
+
+    def upload_scene(self, scene):
+        s = scene
+        self._check(lib().crt_group_upload_scene(self._grp, s.n, _fp(s.center), _fp(s.motion), _fp(s.radius), _ip(s.mat_id), s.m,
+                                                 _ip(s.mat_type), _fp(s.mat_albedo), _fp(s.mat_param)), "crt_group_upload_scene")
+        self.scene = scene
+
+    def build_bvh(self, axis_seed=17):
+        nn = C.c_int32(0)
+        self._check(lib().crt_group_build_bvh(self._grp, axis_seed, C.byref(nn)), "crt_group_build_bvh")
+        return nn.value
+
+    def upload_bvh_nodes(self, nodes):
+        self._check(lib().crt_group_upload_bvh_nodes(self._grp, nodes, len(nodes)), "crt_group_upload_bvh_nodes")
+
+    def set_camera(self, cam):
+        self._check(lib().crt_group_set_camera(self._grp, C.byref(cam)), "crt_group_set_camera")
+        self.cam = cam
+
+    def render(self, world, spp, sample_offset=0, max_depth=50, split=CRT_SPLIT_SAMPLES):
+        fb = np.empty((self.cam.image_height, self.cam.image_width, 3), np.float32)
+        st = RenderStats()
+        self._check(lib().crt_group_render(self._grp, world, spp, sample_offset, max_depth, split, _fp(fb), C.byref(st)),
+                    "crt_group_render")
+        return fb, st

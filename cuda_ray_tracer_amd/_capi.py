@@ -16,10 +16,16 @@ EXPORTS = [
     "crt_bvh_build_host", "crt_create", "crt_destroy", "crt_last_error", "crt_set_seed", "crt_upload_scene",
     "crt_build_bvh", "crt_get_bvh_nodes", "crt_set_camera", "crt_render", "crt_render_accumulate",
     "crt_resolve", "crt_get_stats", "crt_get_kernel_times", "crt_set_count_stats", "crt_trace_samples",
+    "crt_upload_bvh_nodes", "crt_render_accumulate_tiles", "crt_set_arith", "crt_last_kernel_name", "crt_build_id",
+    "crt_group_create", "crt_group_destroy", "crt_group_size", "crt_group_member", "crt_group_last_error",
+    "crt_group_upload_scene", "crt_group_build_bvh", "crt_group_upload_bvh_nodes", "crt_group_set_camera",
+    "crt_group_render",
 ]
 
 CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC = 0, 1, 2
 CRT_WORLD_LIST, CRT_WORLD_BVH = 0, 1
+CRT_ARITH_EXACT, CRT_ARITH_FAST = 0, 1
+CRT_SPLIT_SAMPLES, CRT_SPLIT_TILES = 0, 1
 
 
 class CameraParams(C.Structure):  # crt_camera_params, camera.h:11-22
@@ -86,6 +92,26 @@ def load(path=LIB_PATH):
     lib.crt_resolve.argtypes = [vp, vp, C.c_int32, vp, vp]
     lib.crt_set_count_stats.argtypes = [vp, C.c_int32]
     lib.crt_trace_samples.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, ip, C.c_int32, fp, fp, ip]
+    lib.crt_upload_bvh_nodes.argtypes = [vp, C.POINTER(BvhNode), C.c_int32]
+    lib.crt_render_accumulate_tiles.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    lib.crt_set_arith.argtypes = [vp, C.c_int32]
+    lib.crt_last_kernel_name.restype = C.c_char_p
+    lib.crt_last_kernel_name.argtypes = [vp]
+    lib.crt_build_id.restype = C.c_char_p
+    lib.crt_build_id.argtypes = []
+    lib.crt_group_create.argtypes = [ip, C.c_int32, C.c_uint64, C.POINTER(vp)]
+    lib.crt_group_destroy.argtypes = [vp]
+    lib.crt_group_size.restype = C.c_int32
+    lib.crt_group_size.argtypes = [vp]
+    lib.crt_group_member.restype = vp
+    lib.crt_group_member.argtypes = [vp, C.c_int32]
+    lib.crt_group_last_error.restype = C.c_char_p
+    lib.crt_group_last_error.argtypes = [vp]
+    lib.crt_group_upload_scene.argtypes = [vp, C.c_int32, fp, fp, fp, ip, C.c_int32, ip, fp, fp]
+    lib.crt_group_build_bvh.argtypes = [vp, C.c_uint32, ip]
+    lib.crt_group_upload_bvh_nodes.argtypes = [vp, C.POINTER(BvhNode), C.c_int32]
+    lib.crt_group_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.crt_group_render.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.POINTER(RenderStats)]
     lib.crt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]  # internal, not in the header
     try:  # absent from older builds (CRT_LIB_PATH A/Bs)
         lib.crt_debug_timeline.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]  # internal, not in the header

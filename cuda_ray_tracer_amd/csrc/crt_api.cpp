@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/crt_hip.h"
@@ -23,13 +24,12 @@ struct crt_context {
     // host copies
     int n = 0, m = 0;
     std::vector<float> center, motion, radius;
-    std::vector<crt_bvh_node> nodes;
     int num_leaves = 0;
     crt_camera cam{};
     bool have_cam = false;
     // device
     void* d_pairs = nullptr;
-    crt_bvh_node* d_nodes = nullptr;  // GPU builder: the node array (ctx->nodes is filled from it on demand)
+    crt_bvh_node* d_nodes = nullptr;  // the node array (bvh_world::d_nodes, bvh.h:131), read back by crt_get_bvh_nodes
     double bvh_seconds = 0;
     int bvh_host = 0;  // CRT_BVH_HOST=1: build on the host (crt_host.cpp) instead of the GPU (crt_bvh.hip)
     void* d_spheres = nullptr;
@@ -46,6 +46,9 @@ struct crt_context {
     long launches = 0;
     bool launched = false;
     double wall_seconds = 0;
+    unsigned long long* last_counters = nullptr;  // counters of the last launch (crt_get_stats)
+    int arith = CRT_ARITH_EXACT;
+    char last_kernel[160] = "none";
     // tuning
     int block = 0;  // 0: chosen per launch from the LDS footprint (CRT_BLOCK overrides)
     int tiles_per_wg = 0;  // 0 = auto
@@ -78,6 +81,26 @@ int fail(crt_context* ctx, int code, const std::string& msg) {
 
 float as_float(int32_t bits) { float f; memcpy(&f, &bits, 4); return f; }
 
+// a complete node array (heap order, L leaves) from the host: upload it and derive the child-pair records on the device
+int install_nodes(crt_context* ctx, const crt_bvh_node* nodes, int L) {
+    if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+    if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
+    ctx->num_leaves = 0;
+    const size_t count = 2 * size_t(L) - 1;
+    hipError_t e = hipMalloc((void**)&ctx->d_nodes, count * sizeof(crt_bvh_node));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_pairs, 16 * size_t(L) * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_nodes, nodes, count * sizeof(crt_bvh_node), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = crt_gpu_pairs_from_nodes(ctx->d_nodes, (float*)ctx->d_pairs, L, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
+        if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
+        return fail(ctx, CRT_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
+    }
+    ctx->num_leaves = L;
+    return CRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -87,14 +110,26 @@ const char* crt_last_error(const crt_context* ctx) { return ctx ? ctx->err.c_str
 int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (!out) return fail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_create: out is NULL");
     *out = nullptr;
+    // CRT_TRACE_INIT=1: wall-clock laps of the set-up calls on stderr (where does context creation go?)
+    const bool trace = getenv("CRT_TRACE_INIT") && atoi(getenv("CRT_TRACE_INIT")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "crt_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
+    lap("hipGetDeviceCount");
     if (e != hipSuccess || count <= 0)
         return fail(nullptr, CRT_ERR_NO_DEVICE, std::string("crt_create: no HIP device (") + hipGetErrorString(e) + ")");
     if (device < 0 || device >= count) return fail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_create: device index out of range");
     CRT_HIP_TRY(nullptr, hipSetDevice(device));
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     CRT_HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    lap("hipGetDeviceProperties");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, CRT_ERR_NO_DEVICE, std::string("crt_create: device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
     crt_context* ctx = new crt_context;
@@ -114,18 +149,25 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_UNIT_SAMPLES")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->unit_samples = v; }
     if (const char* b = getenv("CRT_UNIT_FINE")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->fine_samples = v; }
     if (const char* b = getenv("CRT_UNIT_FINE_PCT")) { int v = atoi(b); if (v >= 0 && v <= 100) ctx->fine_pct = v; }
+    if (const char* b = getenv("CRT_ARITH")) ctx->arith = strcmp(b, "fast") == 0 ? CRT_ARITH_FAST : CRT_ARITH_EXACT;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counters, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->d_counters, 0, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess ||
-        false) {
+    if (hipMalloc((void**)&ctx->d_counters, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
     }
+    lap("hipMalloc(counters)");
+    if (hipMemset(ctx->d_counters, 0, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipFree(ctx->d_counters);
+        delete ctx;
+        return fail(nullptr, CRT_ERR_HIP, "crt_create: device memset failed");
+    }
+    lap("hipMemset(counters)");
     for (hipEvent_t& e : ctx->ev_ring)
         if (hipEventCreate(&e) != hipSuccess) {
             crt_destroy(ctx);
             return fail(nullptr, CRT_ERR_HIP, "crt_create: event creation failed");
         }
+    lap("hipEventCreate x128");
     *out = ctx;
     return CRT_OK;
 }
@@ -154,6 +196,20 @@ int crt_set_count_stats(crt_context* ctx, int32_t enable) {
     ctx->census = enable == 2 ? 1 : (enable == 3 ? 2 : 0);  // internal: scheduler census / phase cycles for tools/tune.py
     return CRT_OK;
 }
+
+int crt_set_arith(crt_context* ctx, int32_t arith) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (arith != CRT_ARITH_EXACT && arith != CRT_ARITH_FAST) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_set_arith: unknown mode");
+    ctx->arith = arith;
+    return CRT_OK;
+}
+
+const char* crt_last_kernel_name(const crt_context* ctx) { return ctx ? ctx->last_kernel : "none"; }
+
+#ifndef CRT_BUILD_ID
+#define CRT_BUILD_ID "unknown"
+#endif
+const char* crt_build_id(void) { return CRT_BUILD_ID; }
 
 int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const float* motion, const float* radius,
                      const int32_t* mat_id, int32_t m, const int32_t* mat_type, const float* mat_albedo,
@@ -191,7 +247,7 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
     if (ctx->d_mats) { (void)hipFree(ctx->d_mats); ctx->d_mats = nullptr; }
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
-    ctx->nodes.clear(); ctx->num_leaves = 0;
+    ctx->num_leaves = 0;
     ctx->n = ctx->m = 0;  // no scene until the new one is completely on the device
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_spheres, sph.size() * sizeof(float)));
     CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_mats, mats.size() * sizeof(float)));
@@ -214,7 +270,7 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
     const int L = 1 << depth;
     if (ctx->d_pairs) { (void)hipFree(ctx->d_pairs); ctx->d_pairs = nullptr; }
     if (ctx->d_nodes) { (void)hipFree(ctx->d_nodes); ctx->d_nodes = nullptr; }
-    ctx->nodes.clear(); ctx->num_leaves = 0;
+    ctx->num_leaves = 0;
     if (!ctx->bvh_host) {
         // GPU builder (crt_bvh.hip): boxes and the axis table come from the host code both builders share
         const size_t n = size_t(ctx->n);
@@ -240,37 +296,32 @@ int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out) 
         if (num_nodes_out) *num_nodes_out = int32_t(2 * size_t(L) - 1);
         return CRT_OK;
     }
-    ctx->nodes.resize(2 * size_t(L) - 1);
-    crt::bvh_build(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), axis_seed, ctx->nodes.data());
-    // child-pair records (crt_device.h): record k (1-based heap) holds nodes 2k-1, 2k (0-based)
-    std::vector<float> pairs(16 * size_t(L), 0.0f);
-    auto tag_of = [&](const crt_bvh_node& nd) -> int32_t {
-        if (nd.xmin > nd.xmax) return CRT_TAG_EMPTY;
-        return nd.loc_for_leaf >= 0 ? nd.loc_for_leaf : CRT_TAG_INTERNAL;
-    };
-    if (L == 1) {
-        pairs[12] = pairs[13] = as_float(tag_of(ctx->nodes[0]));  // the root is the only leaf (node 1 = "right" slot of record 0)
-    }
-    for (int k = 1; k < L; ++k) {
-        const crt_bvh_node &l = ctx->nodes[2 * size_t(k) - 1], &r = ctx->nodes[2 * size_t(k)];
-        float* q = &pairs[16 * size_t(k)];
-        q[0] = l.xmin; q[1] = l.xmax; q[2] = r.xmin; q[3] = r.xmax;
-        q[4] = l.ymin; q[5] = l.ymax; q[6] = r.ymin; q[7] = r.ymax;
-        q[8] = l.zmin; q[9] = l.zmax; q[10] = r.zmin; q[11] = r.zmax;
-        q[12] = as_float(tag_of(l)); q[13] = as_float(tag_of(r));
-        // An empty child (reference: interval(+inf,-inf), which a slab test does NOT reject)
-        // is stored as the degenerate far box [BIG,BIG]^3: (BIG - o) * inv gives near == far for a
-        // finite non-zero inv, hence max <= min and a miss without looking at the tag.  Rays with a
-        // non-finite reciprocal take the literal test, which does check the tag.
-        const float BIG = 3.0e38f;
-        if (tag_of(l) == CRT_TAG_EMPTY) { q[0] = q[1] = q[4] = q[5] = q[8] = q[9] = BIG; }
-        if (tag_of(r) == CRT_TAG_EMPTY) { q[2] = q[3] = q[6] = q[7] = q[10] = q[11] = BIG; }
-    }
-    CRT_HIP_TRY(ctx, hipMalloc(&ctx->d_pairs, pairs.size() * sizeof(float)));
-    CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
-    ctx->num_leaves = L;
-    if (num_nodes_out) *num_nodes_out = int32_t(ctx->nodes.size());
+    // host builder (A/B of the GPU builder): the node array goes up as it is, the pair records are derived on the device
+    std::vector<crt_bvh_node> nodes(2 * size_t(L) - 1);
+    crt::bvh_build(ctx->n, ctx->center.data(), ctx->motion.data(), ctx->radius.data(), axis_seed, nodes.data());
+    if (int rc = install_nodes(ctx, nodes.data(), L)) return rc;
+    if (num_nodes_out) *num_nodes_out = int32_t(nodes.size());
     return CRT_OK;
+}
+
+int crt_upload_bvh_nodes(crt_context* ctx, const crt_bvh_node* nodes, int32_t count) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!nodes) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_bvh_nodes: nodes is NULL");
+    if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "crt_upload_bvh_nodes: no scene uploaded");
+    if (crt::bvh_depth(ctx->n) > 28) return fail(ctx, CRT_ERR_TOO_LARGE, "crt_upload_bvh_nodes: tree deeper than 28 levels");
+    const int L = 1 << crt::bvh_depth(ctx->n);
+    if (int64_t(count) != 2 * int64_t(L) - 1)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_bvh_nodes: count is not crt_bvh_num_nodes(n) of the uploaded scene");
+    // the traversal trusts leaf tags as sphere indices: check them here, once
+    for (int j = 0; j < L; ++j) {
+        const crt_bvh_node& nd = nodes[size_t(L) - 1 + j];
+        const bool empty = nd.xmin > nd.xmax;
+        if (!empty && (nd.loc_for_leaf < 0 || nd.loc_for_leaf >= ctx->n))
+            return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_bvh_nodes: leaf with loc_for_leaf outside [0, n)");
+    }
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_TRY(ctx, hipDeviceSynchronize());
+    return install_nodes(ctx, nodes, L);
 }
 
 int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity) {
@@ -278,13 +329,10 @@ int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacit
     if (ctx->num_leaves < 1) return CRT_ERR_STATE;
     const size_t count = 2 * size_t(ctx->num_leaves) - 1;
     if (size_t(capacity) < count) return CRT_ERR_TOO_LARGE;
-    if (ctx->d_nodes) {  // GPU builder: straight from the device array
-        if (hipSetDevice(ctx->device) != hipSuccess ||
-            hipMemcpy(out, ctx->d_nodes, count * sizeof(crt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
-            return CRT_ERR_HIP;
-        return CRT_OK;
-    }
-    memcpy(out, ctx->nodes.data(), count * sizeof(crt_bvh_node));
+    if (!ctx->d_nodes) return CRT_ERR_STATE;
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipMemcpy(out, ctx->d_nodes, count * sizeof(crt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
+        return CRT_ERR_HIP;
     return CRT_OK;
 }
 
@@ -299,7 +347,8 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam) {
     return CRT_OK;
 }
 
-static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int max_depth, unsigned long long* d_sums, crt_render_args& a) {
+static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int max_depth, int tile_stride, int tile_offset,
+                     unsigned long long* d_sums, unsigned long long* counters, crt_render_args& a) {
     if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "render: no camera set");
     if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "render: no scene uploaded");
     if (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: unknown world kind");
@@ -321,18 +370,26 @@ static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int
     if (t == 0) { t = 1; while (t < 16 && int64_t(64) * t * ns < int64_t(16) * block) t <<= 1; }
     a.tiles_per_wg = t;
     a.tiles_x = (c.image_width + 7) / 8; a.tiles_y = (c.image_height + 7) / 8;
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride)
+        return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: tile share needs tile_stride >= 1 and 0 <= tile_offset < tile_stride");
+    const int64_t all_tiles = int64_t(a.tiles_x) * a.tiles_y;
+    a.tile_stride = tile_stride; a.tile_offset = tile_offset;
+    a.n_tiles = int(tile_offset < all_tiles ? (all_tiles - tile_offset + tile_stride - 1) / tile_stride : 0);
     a.max_depth = max_depth;
     a.sched = ctx->sched; a.census = ctx->census; a.run_shift = ctx->run_shift; a.leaf_num = ctx->leaf_num; a.shade_num = ctx->shade_num;
     a.sums = d_sums;
-    a.counters = ctx->d_counters;
+    a.counters = counters;
     return CRT_OK;
 }
 
-int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
-                          int32_t max_depth, int64_t* d_sums, void* stream_) {
+// One render launch: the samples [sample_offset, sample_offset + nsamples) of a tile share, added to d_sums on
+// `stream`; `counters` is the launch's scratch (work-queue counter, statistics, census).
+static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples, int32_t max_depth,
+                             int32_t tile_stride, int32_t tile_offset, int64_t* d_sums, void* stream_,
+                             unsigned long long* counters) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     const int ns_ = nsamples;
-    if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_accumulate: d_sums is NULL");
+    if (!d_sums) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: d_sums is NULL");
     // LDS image of the scene (render_kernel): spheres, and for a BVH world the pair records (simple
     // loop, 64 B per pair) or the sign-sorted plane arrays + leaf tags (scheduled, 96 B + 4 B per pair)
     const bool scheduled = world == CRT_WORLD_BVH && ctx->sched;
@@ -354,11 +411,12 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
     }
     crt_render_args a;
     memset(&a, 0, sizeof a);
-    if (int rc = fill_args(ctx, world, block, sample_offset, nsamples, max_depth, (unsigned long long*)d_sums, a)) return rc;
+    if (int rc = fill_args(ctx, world, block, sample_offset, nsamples, max_depth, tile_stride, tile_offset,
+                           (unsigned long long*)d_sums, counters, a)) return rc;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const int nw = block / 64;
-    const int64_t tiles = int64_t(a.tiles_x) * a.tiles_y;
+    const int64_t tiles = a.n_tiles;  // of this launch's share
     size_t lds = in_lds ? scene_bytes : 48 * size_t(top_pairs);
     int grid;
     if (scheduled && ctx->persist) {
@@ -396,14 +454,34 @@ int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset
         grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
         if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     }
-    CRT_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 32 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 32 * sizeof(unsigned long long), stream));
     const int slot = int(ctx->launches % crt_context::EV_RING);
+    const bool fast = ctx->arith == CRT_ARITH_FAST;
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
-    CRT_HIP_TRY(ctx, crt_launch_render(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
+    if (tiles > 0)  // (a share beyond the last tile is empty: nothing to launch, the statistics read zero)
+        CRT_HIP_TRY(ctx, (fast ? crt_launch_render_fast : crt_launch_render)(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
     ctx->launches += 1;
     ctx->launched = true;
+    ctx->last_counters = counters;
+    const int sched_id = world == CRT_WORLD_BVH ? (ctx->sched ? (ctx->persist ? 2 : 1) : 0) : 0;
+    snprintf(ctx->last_kernel, sizeof ctx->last_kernel, "render_kernel<WORLD=%s, IN_LDS=%d, COUNT=%d, BLOCK=%d, SCHED=%d>%s",
+             world == CRT_WORLD_BVH ? "BVH" : "LIST", int(in_lds), int(ctx->count_stats), block, sched_id, fast ? " [arith=fast]" : "");
     return CRT_OK;
+}
+
+int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
+                          int32_t max_depth, int64_t* d_sums, void* stream) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    return launch_accumulate(ctx, world, sample_offset, nsamples, max_depth, 1, 0, d_sums, stream, ctx->d_counters);
+}
+
+int crt_render_accumulate_tiles(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
+                                int32_t max_depth, int32_t tile_stride, int32_t tile_offset, int64_t* d_sums,
+                                void* stream) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    return launch_accumulate(ctx, world, sample_offset, nsamples, max_depth, tile_stride, tile_offset, d_sums, stream,
+                             ctx->d_counters);
 }
 
 int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream) {
@@ -425,7 +503,7 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     float ms = 0;
     CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
     unsigned long long c[4];
-    CRT_HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(c, ctx->last_counters, sizeof c, hipMemcpyDeviceToHost));
     stats->kernel_seconds = ms * 1e-3;
     stats->wall_seconds = ctx->wall_seconds;
     stats->rays = c[0]; stats->samples = c[1]; stats->pair_visits = c[2]; stats->sphere_tests = c[3];
@@ -452,7 +530,7 @@ int crt_debug_counters(crt_context* ctx, uint64_t* out16) {
     if (!ctx || !out16) return CRT_ERR_INVALID_ARGUMENT;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
-    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(out16, ctx->last_counters ? ctx->last_counters : ctx->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
@@ -498,7 +576,7 @@ int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int3
         return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: bad arguments");
     crt_render_args a;
     memset(&a, 0, sizeof a);
-    if (int rc = fill_args(ctx, world, 512, 0, 1, max_depth, nullptr, a)) return rc;
+    if (int rc = fill_args(ctx, world, 512, 0, 1, max_depth, 1, 0, nullptr, ctx->d_counters, a)) return rc;
     for (int i = 0; i < count; ++i)
         if (px[i] < 0 || px[i] >= ctx->cam.image_width || py[i] < 0 || py[i] >= ctx->cam.image_height || sample[i] < 0)
             return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_trace_samples: pixel or sample out of range");
@@ -518,11 +596,242 @@ int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int3
     CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_px, px, size_t(count) * 4, hipMemcpyHostToDevice));
     CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_py, py, size_t(count) * 4, hipMemcpyHostToDevice));
     CRT_HIP_TRY(ctx, hipMemcpy(ctx->d_smp, sample, size_t(count) * 4, hipMemcpyHostToDevice));
-    CRT_HIP_TRY(ctx, crt_launch_trace_samples(a, world, count, ctx->d_px, ctx->d_py, ctx->d_smp, ctx->d_ray7, ctx->d_rgb, ctx->d_seg, nullptr));
+    CRT_HIP_TRY(ctx, (ctx->arith == CRT_ARITH_FAST ? crt_launch_trace_samples_fast : crt_launch_trace_samples)(a, world, count, ctx->d_px, ctx->d_py, ctx->d_smp, ctx->d_ray7, ctx->d_rgb, ctx->d_seg, nullptr));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
     CRT_HIP_TRY(ctx, hipMemcpy(ray7_out, ctx->d_ray7, size_t(count) * 28, hipMemcpyDeviceToHost));
     CRT_HIP_TRY(ctx, hipMemcpy(rgb_out, ctx->d_rgb, size_t(count) * 12, hipMemcpyDeviceToHost));
     CRT_HIP_TRY(ctx, hipMemcpy(segments_out, ctx->d_seg, size_t(count) * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+
+// ---- several GPUs of one node behind one handle (include/crt_hip.h "crt_group") ---------------------------
+
+}  // extern "C"
+
+struct crt_group {
+    std::vector<crt_context*> members;
+    std::vector<hipStream_t> streams;            // one per member, on its device
+    std::vector<hipEvent_t> done;                // member's sums (or their copy on members[0]'s device) are complete
+    std::vector<unsigned long long*> sums;       // member's own int64 frame, on its device
+    std::vector<unsigned long long*> staging;    // [i-1]: copy of member i's frame on members[0]'s device
+    float* d_fb = nullptr;                       // on members[0]'s device
+    size_t floats = 0;
+    std::string err;
+};
+
+namespace {
+
+std::string g_group_create_error;
+
+int gfail(crt_group* g, int code, const std::string& msg) {
+    if (g) g->err = msg; else g_group_create_error = msg;
+    return code;
+}
+
+// fn(member index) on one host thread per member (the set-up calls are synchronous per context); first failure wins
+template <class F>
+int for_each_member(crt_group* g, const char* what, F fn) {
+    const size_t n = g->members.size();
+    std::vector<int> rc(n, CRT_OK);
+    if (n == 1) rc[0] = fn(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < n; ++i) th.emplace_back([&, i] { rc[i] = fn(int(i)); });
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (rc[i] != CRT_OK)
+            return gfail(g, rc[i], std::string(what) + ": member " + std::to_string(i) + " (device " +
+                                       std::to_string(g->members[i]->device) + "): " + g->members[i]->err);
+    return CRT_OK;
+}
+
+void group_free_frames(crt_group* g) {
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        (void)hipSetDevice(g->members[i]->device);
+        if (i < g->sums.size() && g->sums[i]) { (void)hipFree(g->sums[i]); g->sums[i] = nullptr; }
+    }
+    if (!g->members.empty()) (void)hipSetDevice(g->members[0]->device);
+    for (auto& p : g->staging) if (p) { (void)hipFree(p); p = nullptr; }
+    if (g->d_fb) { (void)hipFree(g->d_fb); g->d_fb = nullptr; }
+    g->floats = 0;
+}
+
+#define CRT_GROUP_TRY(g, expr)                                                                       \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return gfail(g, CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* crt_group_last_error(const crt_group* g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
+
+int crt_group_create(const int32_t* devices, int32_t n, uint64_t seed, crt_group** out) {
+    if (!out) return gfail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_group_create: out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > CRT_GROUP_MAX)
+        return gfail(nullptr, CRT_ERR_INVALID_ARGUMENT, "crt_group_create: device list empty or longer than 16");
+    crt_group* g = new crt_group;
+    for (int i = 0; i < n; ++i) {
+        crt_context* c = nullptr;
+        const int rc = crt_create(devices[i], seed, &c);
+        if (rc != CRT_OK) {
+            const std::string msg = std::string("crt_group_create: device ") + std::to_string(devices[i]) + ": " + crt_last_error(nullptr);
+            crt_group_destroy(g);
+            return gfail(nullptr, rc, msg);
+        }
+        g->members.push_back(c);
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            if (st) (void)hipStreamDestroy(st);
+            crt_group_destroy(g);
+            return gfail(nullptr, CRT_ERR_HIP, "crt_group_create: stream / event creation failed");
+        }
+        g->streams.push_back(st); g->done.push_back(ev);
+    }
+    // peer access from members[0]'s device to the others makes the frame copies direct xGMI transfers; the copies
+    // work without it (staged by the runtime), so a refusal is not an error
+    (void)hipSetDevice(devices[0]);
+    for (int i = 1; i < n; ++i) {
+        int can = 0;
+        if (devices[i] != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // already enabled, or not possible: clear the sticky error
+        }
+    }
+    g->sums.assign(size_t(n), nullptr);
+    g->staging.assign(size_t(n > 1 ? n - 1 : 0), nullptr);
+    *out = g;
+    return CRT_OK;
+}
+
+int crt_group_destroy(crt_group* g) {
+    if (!g) return CRT_OK;
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        (void)hipSetDevice(g->members[i]->device);
+        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        if (i < g->done.size() && g->done[i]) (void)hipEventDestroy(g->done[i]);
+    }
+    group_free_frames(g);
+    for (crt_context* c : g->members) crt_destroy(c);
+    delete g;
+    return CRT_OK;
+}
+
+int32_t crt_group_size(const crt_group* g) { return g ? int32_t(g->members.size()) : 0; }
+
+crt_context* crt_group_member(crt_group* g, int32_t i) {
+    return (g && i >= 0 && size_t(i) < g->members.size()) ? g->members[size_t(i)] : nullptr;
+}
+
+int crt_group_upload_scene(crt_group* g, int32_t n, const float* center, const float* motion, const float* radius,
+                           const int32_t* mat_id, int32_t m, const int32_t* mat_type, const float* mat_albedo,
+                           const float* mat_param) {
+    if (!g) return CRT_ERR_INVALID_ARGUMENT;
+    return for_each_member(g, "crt_group_upload_scene", [&](int i) {
+        return crt_upload_scene(g->members[size_t(i)], n, center, motion, radius, mat_id, m, mat_type, mat_albedo, mat_param);
+    });
+}
+
+int crt_group_build_bvh(crt_group* g, uint32_t axis_seed, int32_t* num_nodes_out) {
+    if (!g) return CRT_ERR_INVALID_ARGUMENT;
+    std::vector<int32_t> nn(g->members.size(), 0);
+    const int rc = for_each_member(g, "crt_group_build_bvh", [&](int i) { return crt_build_bvh(g->members[size_t(i)], axis_seed, &nn[size_t(i)]); });
+    if (rc == CRT_OK && num_nodes_out) *num_nodes_out = nn[0];
+    return rc;
+}
+
+int crt_group_upload_bvh_nodes(crt_group* g, const crt_bvh_node* nodes, int32_t count) {
+    if (!g) return CRT_ERR_INVALID_ARGUMENT;
+    return for_each_member(g, "crt_group_upload_bvh_nodes", [&](int i) { return crt_upload_bvh_nodes(g->members[size_t(i)], nodes, count); });
+}
+
+int crt_group_set_camera(crt_group* g, const crt_camera* cam) {
+    if (!g) return CRT_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < g->members.size(); ++i)
+        if (int rc = crt_set_camera(g->members[i], cam))
+            return gfail(g, rc, std::string("crt_group_set_camera: ") + g->members[i]->err);
+    return CRT_OK;
+}
+
+int crt_group_render(crt_group* g, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth, int32_t split,
+                     float* fb_host, crt_render_stats* stats) {
+    if (!g) return CRT_ERR_INVALID_ARGUMENT;
+    if (!fb_host) return gfail(g, CRT_ERR_INVALID_ARGUMENT, "crt_group_render: fb_host is NULL");
+    if (split != CRT_SPLIT_SAMPLES && split != CRT_SPLIT_TILES) return gfail(g, CRT_ERR_INVALID_ARGUMENT, "crt_group_render: unknown split");
+    if (spp < 1) return gfail(g, CRT_ERR_INVALID_ARGUMENT, "crt_group_render: spp < 1");
+    crt_context* c0 = g->members[0];
+    if (!c0->have_cam) return gfail(g, CRT_ERR_STATE, "crt_group_render: no camera set");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int G = int(g->members.size());
+    const size_t floats = 3 * size_t(c0->cam.image_width) * size_t(c0->cam.image_height);
+    const size_t bytes = floats * sizeof(unsigned long long);
+    if (g->floats != floats) {  // frame buffers: every member's own sums; on members[0]'s device the copies and the fp32 frame
+        group_free_frames(g);
+        for (int i = 0; i < G; ++i) {
+            CRT_GROUP_TRY(g, hipSetDevice(g->members[size_t(i)]->device));
+            CRT_GROUP_TRY(g, hipMalloc((void**)&g->sums[size_t(i)], bytes));
+        }
+        CRT_GROUP_TRY(g, hipSetDevice(c0->device));
+        for (int i = 1; i < G; ++i) CRT_GROUP_TRY(g, hipMalloc((void**)&g->staging[size_t(i) - 1], bytes));
+        CRT_GROUP_TRY(g, hipMalloc((void**)&g->d_fb, floats * sizeof(float)));
+        g->floats = floats;
+    }
+    // every member's share, asynchronously on its own stream: zero, trace, copy to members[0]'s device
+    std::vector<bool> has_work(size_t(G), false);
+    for (int i = 0; i < G; ++i) {
+        crt_context* c = g->members[size_t(i)];
+        CRT_GROUP_TRY(g, hipSetDevice(c->device));
+        hipStream_t st = g->streams[size_t(i)];
+        CRT_GROUP_TRY(g, hipMemsetAsync(g->sums[size_t(i)], 0, bytes, st));
+        int rc = CRT_OK;
+        if (split == CRT_SPLIT_SAMPLES) {
+            const int lo = int(int64_t(i) * spp / G), hi = int(int64_t(i + 1) * spp / G);
+            if (hi > lo) {
+                rc = crt_render_accumulate(c, world, sample_offset + lo, hi - lo, max_depth, (int64_t*)g->sums[size_t(i)], st);
+                has_work[size_t(i)] = true;
+            }
+        } else {
+            rc = crt_render_accumulate_tiles(c, world, sample_offset, spp, max_depth, G, i, (int64_t*)g->sums[size_t(i)], st);
+            has_work[size_t(i)] = true;
+        }
+        if (rc != CRT_OK) return gfail(g, rc, std::string("crt_group_render: member ") + std::to_string(i) + ": " + c->err);
+        if (i > 0)
+            CRT_GROUP_TRY(g, hipMemcpyPeerAsync(g->staging[size_t(i) - 1], c0->device, g->sums[size_t(i)], c->device, bytes, st));
+        CRT_GROUP_TRY(g, hipEventRecord(g->done[size_t(i)], st));
+    }
+    // members[0]: wait for the copies, add them to its own sums, resolve, read back
+    CRT_GROUP_TRY(g, hipSetDevice(c0->device));
+    hipStream_t s0 = g->streams[0];
+    crt_frame_list others; memset(&others, 0, sizeof others);
+    for (int i = 1; i < G; ++i) {
+        CRT_GROUP_TRY(g, hipStreamWaitEvent(s0, g->done[size_t(i)], 0));
+        others.p[others.n++] = g->staging[size_t(i) - 1];
+    }
+    if (others.n > 0) CRT_GROUP_TRY(g, crt_launch_sum_frames(g->sums[0], others, floats, s0));
+    CRT_GROUP_TRY(g, crt_launch_resolve(g->sums[0], g->d_fb, floats, spp, s0));  // camera.h:76 scale
+    CRT_GROUP_TRY(g, hipMemcpyAsync(fb_host, g->d_fb, floats * sizeof(float), hipMemcpyDeviceToHost, s0));
+    CRT_GROUP_TRY(g, hipStreamSynchronize(s0));
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (int i = 0; i < G; ++i) {
+            if (!has_work[size_t(i)]) continue;
+            crt_render_stats st;
+            if (int rc = crt_get_stats(g->members[size_t(i)], &st))
+                return gfail(g, rc, std::string("crt_group_render: statistics of member ") + std::to_string(i) + ": " + g->members[size_t(i)]->err);
+            stats->rays += st.rays; stats->samples += st.samples;
+            stats->pair_visits += st.pair_visits; stats->sphere_tests += st.sphere_tests;
+            if (st.kernel_seconds > stats->kernel_seconds) stats->kernel_seconds = st.kernel_seconds;
+        }
+        stats->wall_seconds = wall;
+    }
     return CRT_OK;
 }
 

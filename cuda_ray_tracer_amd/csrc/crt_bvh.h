@@ -13,4 +13,7 @@
 hipError_t crt_gpu_bvh_build(int n, int depth, const float* d_boxes, const uint8_t* d_axis, crt_bvh_node* d_nodes,
                              float* d_pairs, hipStream_t stream);
 
+// the child-pair records (crt_device.h) of a complete node array with L leaves; asynchronous on `stream`
+hipError_t crt_gpu_pairs_from_nodes(const crt_bvh_node* d_nodes, float* d_pairs, int L, hipStream_t stream);
+
 #endif

@@ -118,6 +118,11 @@ inline unsigned blocks(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+hipError_t crt_gpu_pairs_from_nodes(const crt_bvh_node* d_nodes, float* d_pairs, int L, hipStream_t stream) {
+    hipLaunchKernelGGL(pairs_kernel, dim3(blocks((uint64_t)L)), dim3(256), 0, stream, (float4*)d_pairs, d_nodes, (uint32_t)L);
+    return hipGetLastError();
+}
+
 #define BVH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return e_; } } while (0)
 
 hipError_t crt_gpu_bvh_build(int n_, int depth, const float* d_boxes, const uint8_t* d_axis, crt_bvh_node* d_nodes,

@@ -52,6 +52,9 @@ struct crt_render_args {
     int s0, ns;      // first sample index, sample count of this call
     int tiles_per_wg;  // scheduled kernel: 8x8 tiles per workgroup (power of two)
     int tiles_x, tiles_y;
+    // tile share of this launch (multi-GPU tile split): it traces the 8x8 tiles t = tile_offset + j * tile_stride,
+    // j in [0, n_tiles); the whole frame is stride 1, offset 0, n_tiles = tiles_x * tiles_y
+    int tile_stride, tile_offset, n_tiles;
     int max_depth;
     int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
     int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
@@ -65,10 +68,10 @@ struct crt_render_args {
     int unit_samples;        // samples per coarse unit (1..64)
     int unit_chunks;         // coarse units per tile
     int ns_coarse;           // samples covered by the coarse units (unit_chunks * unit_samples, <= ns)
-    int n_coarse;            // tiles_x * tiles_y * unit_chunks
+    int n_coarse;            // n_tiles * unit_chunks
     int fine_samples;        // samples per fine unit (1..64)
     int fine_chunks;         // fine units per tile = ceil((ns - ns_coarse) / fine_samples)
-    int n_units;             // n_coarse + tiles_x * tiles_y * fine_chunks
+    int n_units;             // n_coarse + n_tiles * fine_chunks
     int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major

@@ -19,8 +19,19 @@
 #include <cmath>
 
 #include "crt_device.h"
+#include "crt_launch.h"
 
+// CRT_FAST=1 (second translation unit, crt_kernels_fast.o; selected per context with crt_set_arith): the same
+// kernels with fp contraction allowed (-ffp-contract=fast) and the slab test re-associated to one fma per plane,
+// t = fma(plane, 1/d, -(o * 1/d)).  Not bit-identical to the oracle; held to the tolerance stated in DESIGN.md.
+#ifndef CRT_FAST
+#define CRT_FAST 0
+#endif
+#if CRT_FAST
+#pragma clang fp contract(fast)
+#else
 #pragma clang fp contract(off)
+#endif
 
 // (packed fp32 -- v_pk_add/mul_f32 -- for the slab products was measured 3-5% slower and is not used; the
 // build also turns the SLP vectorizer off for the same reason, see the Makefile)
@@ -178,10 +189,16 @@ __device__ __forceinline__ bool slab(float bx0, float bx1, float by0, float by1,
 // three reciprocals are finite (then (b - o) * inv is finite or +-inf).  Rays with a non-finite
 // reciprocal (a zero or denormal direction component) take slab() above.
 __device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float by1, float bz0, float bz1, v3 o,
-                                          v3 inv, float lo, float hi) {
+                                          v3 inv, v3 noi, float lo, float hi) {
+#if CRT_FAST
+    const float tx0 = __builtin_fmaf(bx0, inv.x, noi.x), tx1 = __builtin_fmaf(bx1, inv.x, noi.x);
+    const float ty0 = __builtin_fmaf(by0, inv.y, noi.y), ty1 = __builtin_fmaf(by1, inv.y, noi.y);
+    const float tz0 = __builtin_fmaf(bz0, inv.z, noi.z), tz1 = __builtin_fmaf(bz1, inv.z, noi.z);
+#else
     const float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
     const float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
     const float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+#endif
     lo = fmaxf(lo, fminf(tx0, tx1)); hi = fminf(hi, fmaxf(tx0, tx1));
     lo = fmaxf(lo, fminf(ty0, ty1)); hi = fminf(hi, fmaxf(ty0, ty1));
     lo = fmaxf(lo, fminf(tz0, tz1)); hi = fminf(hi, fmaxf(tz0, tz1));
@@ -438,7 +455,8 @@ __device__ __forceinline__ void unit_next(const crt_render_args& a, unsigned lon
         const uint32_t v = fine ? u - (uint32_t)a.n_coarse : u;
         const uint32_t chunks = (uint32_t)(fine ? a.fine_chunks : a.unit_chunks);
         const uint32_t size = (uint32_t)(fine ? a.fine_samples : a.unit_samples);
-        const uint32_t tile = v / chunks, chunk = v - tile * chunks;
+        const uint32_t share_tile = v / chunks, chunk = v - share_tile * chunks;
+        const uint32_t tile = share_tile * (uint32_t)a.tile_stride + (uint32_t)a.tile_offset;  // this launch's tile share
         const uint32_t ty = tile / (uint32_t)a.tiles_x, tx = tile - ty * (uint32_t)a.tiles_x;
         const uint32_t first = (fine ? (uint32_t)a.ns_coarse : 0u) + chunk * size;
         const uint32_t left = (uint32_t)a.ns - first;  // coarse chunks are all full (ns_coarse <= ns)
@@ -477,6 +495,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     path_t p;
     p.r.o = mk(0, 0, 0); p.r.d = mk(0, 0, 1); p.r.tm = 0; p.thr = mk(1, 1, 1); p.sky_a = 0; p.depth = 0;
     v3 inv = mk(1, 1, 1);
+    v3 noi = mk(0, 0, 0);  // CRT_FAST: -(origin * inv), the addend of the slab fma
     float ray_a = 1.0f, best_t = __builtin_huge_valf();
     int best_obj = -1;
     // The traversal state IS the node index k (1-based heap order, NL = number of leaves):
@@ -549,12 +568,21 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const float4 ax = *(const float4*)(planes + ((k << 4) + offx));
                         const float4 ay = *(const float4*)(planes + ((k << 4) + offy));
                         const float4 az = *(const float4*)(planes + ((k << 4) + offz));
+#if CRT_FAST
+                        const float nLx = __builtin_fmaf(ax.x, inv.x, noi.x), fLx = __builtin_fmaf(ax.y, inv.x, noi.x);
+                        const float nRx = __builtin_fmaf(ax.z, inv.x, noi.x), fRx = __builtin_fmaf(ax.w, inv.x, noi.x);
+                        const float nLy = __builtin_fmaf(ay.x, inv.y, noi.y), fLy = __builtin_fmaf(ay.y, inv.y, noi.y);
+                        const float nRy = __builtin_fmaf(ay.z, inv.y, noi.y), fRy = __builtin_fmaf(ay.w, inv.y, noi.y);
+                        const float nLz = __builtin_fmaf(az.x, inv.z, noi.z), fLz = __builtin_fmaf(az.y, inv.z, noi.z);
+                        const float nRz = __builtin_fmaf(az.z, inv.z, noi.z), fRz = __builtin_fmaf(az.w, inv.z, noi.z);
+#else
                         const float nLx = (ax.x - p.r.o.x) * inv.x, fLx = (ax.y - p.r.o.x) * inv.x;
                         const float nRx = (ax.z - p.r.o.x) * inv.x, fRx = (ax.w - p.r.o.x) * inv.x;
                         const float nLy = (ay.x - p.r.o.y) * inv.y, fLy = (ay.y - p.r.o.y) * inv.y;
                         const float nRy = (ay.z - p.r.o.y) * inv.y, fRy = (ay.w - p.r.o.y) * inv.y;
                         const float nLz = (az.x - p.r.o.z) * inv.z, fLz = (az.y - p.r.o.z) * inv.z;
                         const float nRz = (az.z - p.r.o.z) * inv.z, fRz = (az.w - p.r.o.z) * inv.z;
+#endif
                         const float loL = fmaxf(fmaxf(fmaxf(nLx, nLy), nLz), tmin), hiL = fminf(fminf(fminf(fLx, fLy), fLz), best_t);
                         const float loR = fmaxf(fmaxf(fmaxf(nRx, nRy), nRz), tmin), hiR = fminf(fminf(fminf(fRx, fRy), fRz), best_t);
                         hitL = !(hiL <= loL);
@@ -578,8 +606,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
 #else
                         q0 = q1 = q2 = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
 #endif
-                        hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
-                        hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
+                        hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, noi, tmin, best_t);
+                        hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, noi, tmin, best_t);
                     }
                     // branch-free successor: descend (left first, right remembered) -- onto a leaf:
                     // hold it for the sphere phase -- or pop the nearest pending right sibling
@@ -881,6 +909,9 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     } else {
                         inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
                         exact = !finite3(inv);
+#if CRT_FAST
+                        noi = mk(-(p.r.o.x * inv.x), -(p.r.o.y * inv.y), -(p.r.o.z * inv.z));
+#endif
                         if (IN_LDS) {
                             offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
                             offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
@@ -970,10 +1001,11 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         int2* origin = (int2*)(acc + 192 * T);
         uint32_t* counter = (uint32_t*)(origin + T);
         for (int i = threadIdx.x; i < 192 * T; i += BLOCK) acc[i] = 0ull;
-        if (threadIdx.x < T) {
-            const int tile = blockIdx.x * T + threadIdx.x;
+        if ((int)threadIdx.x < T) {
+            const int share_tile = blockIdx.x * T + threadIdx.x;
+            const int tile = share_tile * a.tile_stride + a.tile_offset;
             const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-            origin[threadIdx.x] = make_int2(ty < a.tiles_y ? tx * 8 : -1, ty * 8);
+            origin[threadIdx.x] = make_int2(share_tile < a.n_tiles ? tx * 8 : -1, ty * 8);
         }
         if (threadIdx.x == 0) *counter = 0u;
         __syncthreads();
@@ -995,10 +1027,11 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         // simple loop: a wave owns one tile, a lane one pixel and all its samples (brute-force list
         // world, and the A/B reference of the scheduler)
         if (IN_LDS) __syncthreads();
-        const int tile = blockIdx.x * NW + wave;
+        const int share_tile = blockIdx.x * NW + wave;
+        const int tile = share_tile * a.tile_stride + a.tile_offset;
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-        const bool valid = (ty < a.tiles_y) && (px < a.cam.width) && (py < a.cam.height);
+        const bool valid = (share_tile < a.n_tiles) && (px < a.cam.width) && (py < a.cam.height);
         const uint32_t pixel_index = (uint32_t)(py * a.cam.width + px);
         if (valid) {
             unsigned long long sx = 0, sy = 0, sz = 0;
@@ -1051,6 +1084,14 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
 __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* sums, float* fb, size_t count, double scale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) fb[i] = (float)((double)(long long)sums[i] * scale);
+}
+
+__global__ __launch_bounds__(256) void sum_frames_kernel(unsigned long long* dst, const crt_frame_list src, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    unsigned long long v = dst[i];
+    for (int j = 0; j < src.n; ++j) v += src.p[j][i];
+    dst[i] = v;
 }
 
 // single paths, for fine-grained parity checks (same device functions as the render kernel)
@@ -1123,6 +1164,7 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
 
 }  // namespace
 
+#if !CRT_FAST
 hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream) {
     const double scale = ldexp(1.0, -40) / (double)spp;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
@@ -1130,8 +1172,20 @@ hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp
     return hipGetLastError();
 }
 
+// dst[i] += src[0][i] + ... + src[n-1][i]: the frames of a group's other members (crt_group_render), integer sums
+hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& src, size_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_frames_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, dst, src, count);
+    return hipGetLastError();
+}
+#define crt_launch_render_tu crt_launch_render
+#define crt_launch_trace_samples_tu crt_launch_trace_samples
+#else
+#define crt_launch_render_tu crt_launch_render_fast
+#define crt_launch_trace_samples_tu crt_launch_trace_samples_fast
+#endif
+
 // Host-visible launchers (called from crt_api.cpp)
-hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
+hipError_t crt_launch_render_tu(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
                              size_t lds_bytes, hipStream_t stream) {
     if (world == 1) {
         if (in_lds) return count ? launch_block<1, true, true>(a, block, grid, lds_bytes, stream)
@@ -1145,7 +1199,7 @@ hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, b
                  : launch_block<0, false, false>(a, block, grid, lds_bytes, stream);
 }
 
-hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
+hipError_t crt_launch_trace_samples_tu(const crt_render_args& a, int world, int count, const int* px, const int* py,
                                     const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream) {
     const int grid = (count + 63) / 64;
     if (world == 1) hipLaunchKernelGGL(trace_samples_kernel<1>, dim3(grid), dim3(64), 0, stream, a, count, px, py, samples, ray7, rgb, segments);

@@ -8,6 +8,15 @@
 
 hipError_t crt_launch_render(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
                              size_t lds_bytes, hipStream_t stream);
+// the same kernels compiled with fp contraction and the fma slab test (crt_kernels.hip with CRT_FAST=1)
+hipError_t crt_launch_render_fast(const crt_render_args& a, int world, bool in_lds, bool count, int block, int grid,
+                                  size_t lds_bytes, hipStream_t stream);
+hipError_t crt_launch_trace_samples_fast(const crt_render_args& a, int world, int count, const int* px, const int* py,
+                                         const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream);
+// dst[i] += sum over the listed frames (int64 fixed-point sums of a group's other members)
+#define CRT_GROUP_MAX 16
+struct crt_frame_list { const unsigned long long* p[CRT_GROUP_MAX]; int n; };
+hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& src, size_t count, hipStream_t stream);
 hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream);
 hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
                                     const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream);

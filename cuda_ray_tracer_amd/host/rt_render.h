@@ -7,60 +7,37 @@
 // PPM through cam->display_frame() and return the seconds around launch + sync by reference.
 // Errors behave like cudaCheckErrors (main_experimental.cu:13-23): message on stderr, exit(1).
 // The reference seeds cuRAND with time(0); here the seed is crt_host_seed() (default 1, or the
-// environment variable CRT_SEED) so that runs are reproducible.
+// environment variable CRT_SEED) so that runs are reproducible.  With CRT_DEVICES="0,1,..." (rt_main --gpus N) one
+// image is split over several GPUs of the node (crt_group_*, BASELINE.json configs[2]); the frame is bit-identical.
 #ifndef CRT_HOST_RT_RENDER_H
 #define CRT_HOST_RT_RENDER_H
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/crt_hip.h"
 #include "rt_camera.h"
 #include "rt_scene.h"
 
-#define crtCheckErrors(ctx, rc, msg)                                                                         \
-    do {                                                                                                     \
-        if ((rc) != CRT_OK) {                                                                                \
-            fprintf(stderr, "Fatal error: %s (%s at %s:%d)\n", msg, crt_last_error(ctx), __FILE__, __LINE__); \
-            fprintf(stderr, "*** FAILED - ABORTING\n");                                                      \
-            exit(1);                                                                                         \
-        }                                                                                                    \
-    } while (0)
-
-inline uint64_t& crt_host_seed() {
-    static uint64_t seed = getenv("CRT_SEED") ? strtoull(getenv("CRT_SEED"), nullptr, 10) : 1ull;
-    return seed;
-}
-inline int& crt_host_device() {
-    static int device = getenv("CRT_DEVICE") ? atoi(getenv("CRT_DEVICE")) : 0;
-    return device;
+inline int crt_host_split() {  // CRT_SPLIT=tiles: 8x8-tile shares instead of sample ranges (several GPUs only)
+    const char* s = getenv("CRT_SPLIT");
+    return (s && strcmp(s, "tiles") == 0) ? CRT_SPLIT_TILES : CRT_SPLIT_SAMPLES;
 }
 
-// shared tail of render() / render_experimental()
-inline void crt_render_flat(const crt_flat_scene& flat, int world_kind, camera* cam, float& timer_seconds) {
-    crt_context* ctx = nullptr;
-    int rc = crt_create(crt_host_device(), crt_host_seed(), &ctx);
-    crtCheckErrors(nullptr, rc, "device context creation failed");
-    rc = crt_upload_scene(ctx, flat.num_objects(), flat.center.data(), flat.motion.data(), flat.radius.data(),
-                          flat.mat_id.data(), int32_t(flat.mat_type.size()), flat.mat_type.data(),
-                          flat.mat_albedo.data(), flat.mat_param.data());
-    crtCheckErrors(ctx, rc, "scene upload failed");
-    if (world_kind == CRT_WORLD_BVH) {
-        int32_t nodes = 0;
-        rc = crt_build_bvh(ctx, 17u, &nodes);
-        crtCheckErrors(ctx, rc, "BVH build failed");
-    }
-    rc = crt_set_camera(ctx, &cam->get_derived());
-    crtCheckErrors(ctx, rc, "camera upload failed");
+// shared tail of render() / render_experimental(): `group` holds the scene (and the BVH for the BVH world)
+inline void crt_render_group(crt_group* group, int world_kind, camera* cam, float& timer_seconds) {
+    for (int32_t i = 0; i < crt_group_size(group); ++i) crt_set_seed(crt_group_member(group, i), crt_host_seed());
+    int rc = crt_group_set_camera(group, &cam->get_derived());
+    crtCheckErrors(crt_group_last_error(group), rc, "camera upload failed");
     std::vector<vec3> frame_buffer(size_t(cam->image_width) * size_t(cam->get_image_height()));
     crt_render_stats stats;
-    rc = crt_render(ctx, world_kind, cam->samples_per_pixel, 0, cam->max_depth,
-                    reinterpret_cast<float*>(frame_buffer.data()), &stats);
-    crtCheckErrors(ctx, rc, "kernel launch error");
+    rc = crt_group_render(group, world_kind, cam->samples_per_pixel, 0, cam->max_depth, crt_host_split(),
+                          reinterpret_cast<float*>(frame_buffer.data()), &stats);
+    crtCheckErrors(crt_group_last_error(group), rc, "kernel launch error");
     cam->display_frame(frame_buffer.data());
     timer_seconds = float(stats.wall_seconds);
-    crt_destroy(ctx);
 }
 
 // helper.h:111-115
@@ -68,14 +45,28 @@ inline void render(int pixels_per_block_x, int pixels_per_block_y, camera* cam, 
     (void)pixels_per_block_x; (void)pixels_per_block_y;  // launch geometry is the library's business
     crt_flat_scene flat;
     (*world)->flatten(flat);
-    crt_render_flat(flat, CRT_WORLD_LIST, cam, timer_seconds);
+    const std::vector<int32_t>& devices = crt_host_devices();
+    crt_group* group = nullptr;
+    int rc = crt_group_create(devices.data(), int32_t(devices.size()), crt_host_seed(), &group);
+    crtCheckErrors(crt_group_last_error(nullptr), rc, "device context creation failed");
+    rc = crt_group_upload_scene(group, flat.num_objects(), flat.center.data(), flat.motion.data(), flat.radius.data(),
+                                flat.mat_id.data(), int32_t(flat.mat_type.size()), flat.mat_type.data(),
+                                flat.mat_albedo.data(), flat.mat_param.data());
+    crtCheckErrors(crt_group_last_error(group), rc, "scene upload failed");
+    crt_render_group(group, CRT_WORLD_LIST, cam, timer_seconds);
+    crt_group_destroy(group);
 }
 
-// helper_experimental.h:148-152
+// helper_experimental.h:148-152.  The scene and the tree are already on the GPUs (bvh_world's constructor).
 inline void render_experimental(int pixels_per_block_x, int pixels_per_block_y, camera* cam, bvh_world* world,
                                 float& timer_seconds) {
     (void)pixels_per_block_x; (void)pixels_per_block_y;
-    crt_render_flat(world->flat, CRT_WORLD_BVH, cam, timer_seconds);
+    if (!world->group) {
+        fprintf(stderr, "Fatal error: device context creation failed (bvh_world was built without a GPU at %s:%d)\n", __FILE__, __LINE__);
+        fprintf(stderr, "*** FAILED - ABORTING\n");
+        exit(1);
+    }
+    crt_render_group(world->group, CRT_WORLD_BVH, cam, timer_seconds);
 }
 
 // Builds host objects from the flat arrays of the library's scene generators.

@@ -10,6 +10,9 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <unordered_map>
 #include <vector>
 
@@ -169,9 +172,48 @@ class bvh_node {
 };
 static_assert(sizeof(bvh_node) == sizeof(crt_bvh_node), "bvh_node must match crt_bvh_node");
 
-// bvh.h:126-192.  The constructor flattens the objects, sorts and builds the node array with the
-// library's builder (bit-identical to the reference algorithm under the documented tie rule) and
-// keeps the nodes in host memory; render_experimental() hands the same scene to the GPU.
+// Process-wide settings of the host mirror.  The reference seeds cuRAND with time(0) (helper.h:134) and uses the
+// current CUDA device; here the seed is crt_host_seed() (default 1, or the environment variable CRT_SEED) so that
+// runs are reproducible, and the GPUs are crt_host_devices(): CRT_DEVICES="0,1,2,3" (one image split over them), else
+// the single device CRT_DEVICE (default 0).
+inline uint64_t& crt_host_seed() {
+    static uint64_t seed = getenv("CRT_SEED") ? strtoull(getenv("CRT_SEED"), nullptr, 10) : 1ull;
+    return seed;
+}
+inline std::vector<int32_t>& crt_host_devices() {
+    static std::vector<int32_t> devices = [] {
+        std::vector<int32_t> d;
+        if (const char* list = getenv("CRT_DEVICES")) {
+            for (const char* p = list; *p;) {
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                d.push_back(int32_t(v));
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (d.empty()) d.push_back(getenv("CRT_DEVICE") ? atoi(getenv("CRT_DEVICE")) : 0);
+        return d;
+    }();
+    return devices;
+}
+
+// errors behave like cudaCheckErrors (main_experimental.cu:13-23): message on stderr, exit(1)
+#define crtCheckErrors(msg_source, rc, msg)                                                                  \
+    do {                                                                                                     \
+        if ((rc) != CRT_OK) {                                                                                \
+            fprintf(stderr, "Fatal error: %s (%s at %s:%d)\n", msg, (msg_source), __FILE__, __LINE__);        \
+            fprintf(stderr, "*** FAILED - ABORTING\n");                                                      \
+            exit(1);                                                                                         \
+        }                                                                                                    \
+    } while (0)
+
+// bvh.h:126-192.  Like the reference's, the constructor builds the tree ON THE DEVICE: it flattens the objects,
+// hands them to the GPUs of crt_host_devices() (crt_group), builds the node array there (crt_bvh.hip: one stable
+// sort per tree level, bit-identical to the reference's recursion under the documented tie rule) and reads it back
+// into the public d_nodes (host memory here).  The group keeps scene and tree, so render_experimental() renders
+// without building anything again.  A process that has no GPU at all (host-side tools, the CPU test-suite) gets the
+// same node array from the library's host builder and no group; rendering then fails like any launch without a device.
 class bvh_world {
   public:
     int num_objects;
@@ -179,18 +221,37 @@ class bvh_world {
     int num_nodes;
     bvh_node* d_nodes;
     crt_flat_scene flat;
+    crt_group* group = nullptr;
 
     bvh_world(hittable** object_list, int list_length)
         : num_objects(list_length), d_objects(object_list), num_nodes(0), d_nodes(nullptr) {
         for (int i = 0; i < list_length; ++i) object_list[i]->flatten(flat);
         num_nodes = crt_bvh_num_nodes(flat.num_objects());
-        if (num_nodes > 0) {
-            d_nodes = new bvh_node[num_nodes];
+        if (num_nodes <= 0) return;
+        d_nodes = new bvh_node[num_nodes];
+        const std::vector<int32_t>& devices = crt_host_devices();
+        int rc = crt_group_create(devices.data(), int32_t(devices.size()), crt_host_seed(), &group);
+        if (rc == CRT_ERR_NO_DEVICE) {
+            group = nullptr;
             crt_bvh_build_host(flat.num_objects(), flat.center.data(), flat.motion.data(), flat.radius.data(), 17u,
                                reinterpret_cast<crt_bvh_node*>(d_nodes));  // seed 17: bvh.h:144
+            return;
         }
+        crtCheckErrors(crt_group_last_error(nullptr), rc, "device context creation failed");
+        rc = crt_group_upload_scene(group, flat.num_objects(), flat.center.data(), flat.motion.data(), flat.radius.data(),
+                                    flat.mat_id.data(), int32_t(flat.mat_type.size()), flat.mat_type.data(),
+                                    flat.mat_albedo.data(), flat.mat_param.data());
+        crtCheckErrors(crt_group_last_error(group), rc, "scene upload failed");
+        int32_t built = 0;
+        rc = crt_group_build_bvh(group, 17u, &built);
+        crtCheckErrors(crt_group_last_error(group), rc, "BVH build failed");
+        rc = crt_get_bvh_nodes(crt_group_member(group, 0), reinterpret_cast<crt_bvh_node*>(d_nodes), num_nodes);
+        crtCheckErrors(crt_last_error(crt_group_member(group, 0)), rc, "BVH read-back failed");
     }
-    ~bvh_world() { delete[] d_nodes; }  // bvh.h:194
+    ~bvh_world() {  // bvh.h:194
+        delete[] d_nodes;
+        crt_group_destroy(group);
+    }
     bvh_world(const bvh_world&) = delete;
     bvh_world& operator=(const bvh_world&) = delete;
 };

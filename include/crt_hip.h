@@ -36,6 +36,17 @@ extern "C" {
 #define CRT_METAL 1
 #define CRT_DIELECTRIC 2
 
+/* arithmetic of the render kernels (crt_set_arith) */
+#define CRT_ARITH_EXACT 0 /* every fp32 operation rounded separately, in the order of the reference's C++ expressions:
+                             a path is bit-identical to the CPU oracle (the parity suite's mode; default) */
+#define CRT_ARITH_FAST 1  /* the slab test contracted to fused multiply-adds, t = fma(plane, 1/d, -o/d): what nvcc's
+                             default -fmad=true does to aabb.h:48-62; images agree with EXACT within the tolerance
+                             stated in DESIGN.md, not bit for bit */
+
+/* how crt_group_render cuts one image over the group's devices */
+#define CRT_SPLIT_SAMPLES 0 /* member g traces samples [g spp/G, (g+1) spp/G) of every pixel (north_star) */
+#define CRT_SPLIT_TILES 1   /* member g traces every sample of the 8x8 tiles t = g mod G */
+
 /* which `world` the bounce loop queries */
 #define CRT_WORLD_LIST 0 /* hittable_list::hit, hittable_list.h:43-58  (render(),              helper.h:111)             */
 #define CRT_WORLD_BVH 1  /* external_hit,       helper_experimental.h:1-50 (render_experimental(), helper_experimental.h:148) */
@@ -141,6 +152,12 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
 int crt_build_bvh(crt_context* ctx, uint32_t axis_seed, int32_t* num_nodes_out);
 /* read-back of bvh_world::d_nodes (bvh.h:131) for the bit-exact check */
 int crt_get_bvh_nodes(const crt_context* ctx, crt_bvh_node* out, int32_t capacity);
+/* The other half of "build or upload": hands the context a node array the caller already holds (the public
+ * bvh_world::d_nodes / num_nodes of bvh.h:129-131, e.g. from crt_bvh_build_host or read back from another
+ * context) instead of building it again.  `count` must be crt_bvh_num_nodes(n) for the uploaded scene, nodes in
+ * heap order (root 0, children of i at 2i+1 / 2i+2, bvh.h:87-95); leaves carry loc_for_leaf in [0, n) or an
+ * empty box (min > max, bvh.h:82).  Boxes are taken as given. */
+int crt_upload_bvh_nodes(crt_context* ctx, const crt_bvh_node* nodes, int32_t count);
 
 /* the managed `camera*` the kernels dereference (main_experimental.cu:99-116) */
 int crt_set_camera(crt_context* ctx, const crt_camera* cam);
@@ -167,6 +184,15 @@ int crt_render(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offs
 int crt_render_accumulate(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
                           int32_t max_depth, int64_t* d_sums, void* stream);
 
+/* crt_render_accumulate restricted to a share of the frame's 8x8 tiles (row-major tile index t over
+ * ceil(W/8) x ceil(H/8)): traces the tiles t = tile_offset + j * tile_stride only.  tile_stride >= 1,
+ * 0 <= tile_offset < tile_stride; (1, 0) is the whole frame.  The multi-GPU tile split (BASELINE.json
+ * configs[4] "per-GPU tile/sample balancing"): member g of G calls it with (G, g); the shares are disjoint and
+ * their union is the frame.  No counterpart in the reference (single GPU, helper.h:111-171). */
+int crt_render_accumulate_tiles(crt_context* ctx, int32_t world, int32_t sample_offset, int32_t nsamples,
+                                int32_t max_depth, int32_t tile_stride, int32_t tile_offset, int64_t* d_sums,
+                                void* stream);
+
 /* cam.pixel_samples_scale (camera.h:76, render_with_cuda.h:164): device buffer of fixed-point
  * sums over `spp` samples -> fp32 frame, fb[i] = (float)((double)d_sums[i] * (2^-40 / spp)). */
 int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream);
@@ -182,12 +208,44 @@ int crt_get_kernel_times(crt_context* ctx, int32_t count, double* seconds_out);
 /* enable (1) / disable (0) the pair_visits / sphere_tests counters (slower kernel variant) */
 int crt_set_count_stats(crt_context* ctx, int32_t enable);
 
+/* CRT_ARITH_EXACT (default; the environment variable CRT_ARITH=fast changes the default) or CRT_ARITH_FAST */
+int crt_set_arith(crt_context* ctx, int32_t arith);
+
+/* Which code ran: template instance of the render kernel of the last launch on ctx ("render_kernel<...>", static
+ * string) and a hash of the kernel sources this library was built from (bench.py ties committed profiles to it). */
+const char* crt_last_kernel_name(const crt_context* ctx);
+const char* crt_build_id(void);
+
 /* Debug/parity: primary ray (7 floats), radiance (3 floats) and number of closest-hit
  * queries of single (pixel, sample) paths, computed by the same device functions as the
  * render kernel.  px/py/sample are arrays of `count` entries; outputs are host buffers. */
 int crt_trace_samples(crt_context* ctx, int32_t world, int32_t count, const int32_t* px, const int32_t* py,
                       const int32_t* sample, int32_t max_depth, float* ray7_out, float* rgb_out,
                       int32_t* segments_out);
+
+/* ---- several GPUs of one node behind one handle ------------------------------------------- */
+
+/* The reference is single-GPU (helper_experimental.h:148-213); BASELINE.json configs[2] splits one image over the
+ * GPUs of a node.  A group holds one context per entry of `devices` (an index may repeat: contexts then share that
+ * GPU); scene, BVH and camera calls go to every member (on one host thread each), crt_group_render cuts the image
+ * by `split`, traces the shares concurrently, sums the int64 buffers on devices[0] (peer copies over xGMI + one
+ * add kernel; integer sums, so the frame is bit-identical to a single context's for every group size and either
+ * split) and writes the normalised frame to the caller's host buffer like crt_render.  stats: rays / samples /
+ * counters summed over the members, kernel_seconds = the slowest member's launch. */
+typedef struct crt_group crt_group;
+int crt_group_create(const int32_t* devices, int32_t n, uint64_t seed, crt_group** out);
+int crt_group_destroy(crt_group* grp);
+int32_t crt_group_size(const crt_group* grp);
+crt_context* crt_group_member(crt_group* grp, int32_t i); /* for the per-context calls (knobs, statistics) */
+const char* crt_group_last_error(const crt_group* grp);   /* grp == NULL: last failed crt_group_create */
+int crt_group_upload_scene(crt_group* grp, int32_t n, const float* center, const float* motion, const float* radius,
+                           const int32_t* mat_id, int32_t m, const int32_t* mat_type, const float* mat_albedo,
+                           const float* mat_param);
+int crt_group_build_bvh(crt_group* grp, uint32_t axis_seed, int32_t* num_nodes_out);
+int crt_group_upload_bvh_nodes(crt_group* grp, const crt_bvh_node* nodes, int32_t count);
+int crt_group_set_camera(crt_group* grp, const crt_camera* cam);
+int crt_group_render(crt_group* grp, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
+                     int32_t split, float* fb_host, crt_render_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -48,3 +48,18 @@ def test_cli_ppm_matches_oracle(crt, orc):
         sums, _ = orc.render(osc, cam, 5, 0, 32, 50, nodes, nthreads=8)
         want = orc.write_ppm(orc.resolve(sums, 32))
         assert r.stdout == want
+        if scene == "random":
+            # the device list of the C++ boundary: three contexts sharing this box's one GPU, tile shares
+            env = dict(os.environ, CRT_DEVICES="0,0,0", CRT_SPLIT="tiles")
+            r3 = subprocess.run([exe, "--width", "64", "--samples", "10", "--seed", "5", "--scene", scene, "--world", world],
+                                capture_output=True, timeout=120, env=env)
+            assert r3.returncode == 0, r3.stderr.decode()
+            assert r3.stdout == want
+            env = dict(os.environ, CRT_DEVICES="0,0")
+            r2 = subprocess.run([exe, "--width", "64", "--samples", "10", "--seed", "5", "--scene", scene, "--world", "list"],
+                                capture_output=True, timeout=120, env=env)
+            assert r2.returncode == 0, r2.stderr.decode()
+    bad = subprocess.run([exe, "--width", "32", "--samples", "1", "--gpus", "64"], capture_output=True, timeout=60)
+    assert bad.returncode == 1 and b"Invalid --gpus" in bad.stderr
+    none = subprocess.run([exe, "--width", "32", "--samples", "1", "--gpu", "99"], capture_output=True, timeout=60)
+    assert none.returncode == 1 and b"FAILED - ABORTING" in none.stderr  # cudaCheckErrors behaviour, main_experimental.cu:13-23
