@@ -47,8 +47,19 @@ __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y -
 __device__ __forceinline__ v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ v3 operator*(float t, v3 a) { return mk(t * a.x, t * a.y, t * a.z); }
 __device__ __forceinline__ v3 operator*(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+#if CRT_FAST
+// contraction spelled out for the two primitives that the same logical value can reach through different code paths
+// (a rejection-sampling attempt is judged in the shade phase's block loop or in its whole-wave tail pass, depending on
+// scheduling): left to the compiler, the two sites could fuse differently and the frame would depend on scheduling
+__device__ __forceinline__ float sum3(float xx, float y, float z) { return __builtin_fmaf(z, z, __builtin_fmaf(y, y, xx)); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float len2(v3 a) { return sum3(a.x * a.x, a.y, a.z); }
+#else
 __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+#endif
+// squared length of a rejection-sampling attempt (vec3.h:147-149,156-158: x*x + y*y + z*z, z = 0 for the disk)
+__device__ __forceinline__ float lensq3(float x, float y, float z) { return len2(mk(x, y, z)); }
 // vec3.h:114-116,130-132: v / t == (1/t) * v
 __device__ __forceinline__ v3 unit(v3 a) { return (1.0f / sqrtf(len2(a))) * a; }
 
@@ -98,9 +109,9 @@ __device__ __forceinline__ void random_in_unit_disk(stream& rs, float& dx, float
     for (;;) {
         const float4 b = rs.next_block();
         float x = rf11(b.x), y = rf11(b.y);
-        if (x * x + y * y + 0.0f * 0.0f < 1.0f) { dx = x; dy = y; return; }
+        if (lensq3(x, y, 0.0f) < 1.0f) { dx = x; dy = y; return; }
         x = rf11(b.z); y = rf11(b.w);
-        if (x * x + y * y + 0.0f * 0.0f < 1.0f) { dx = x; dy = y; return; }
+        if (lensq3(x, y, 0.0f) < 1.0f) { dx = x; dy = y; return; }
     }
 }
 
@@ -495,7 +506,6 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     path_t p;
     p.r.o = mk(0, 0, 0); p.r.d = mk(0, 0, 1); p.r.tm = 0; p.thr = mk(1, 1, 1); p.sky_a = 0; p.depth = 0;
     v3 inv = mk(1, 1, 1);
-    v3 noi = mk(0, 0, 0);  // CRT_FAST: -(origin * inv), the addend of the slab fma
     float ray_a = 1.0f, best_t = __builtin_huge_valf();
     int best_obj = -1;
     // The traversal state IS the node index k (1-based heap order, NL = number of leaves):
@@ -569,6 +579,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const float4 ay = *(const float4*)(planes + ((k << 4) + offy));
                         const float4 az = *(const float4*)(planes + ((k << 4) + offz));
 #if CRT_FAST
+                        // -(o * inv) is formed here, per step (3 multiplies against the 12 subtractions saved), rather
+                        // than kept in three more registers across the whole state machine: 81 VGPRs would cost the
+                        // second workgroup per CU
+                        const v3 noi = mk(-(p.r.o.x * inv.x), -(p.r.o.y * inv.y), -(p.r.o.z * inv.z));
                         const float nLx = __builtin_fmaf(ax.x, inv.x, noi.x), fLx = __builtin_fmaf(ax.y, inv.x, noi.x);
                         const float nRx = __builtin_fmaf(ax.z, inv.x, noi.x), fRx = __builtin_fmaf(ax.w, inv.x, noi.x);
                         const float nLy = __builtin_fmaf(ay.x, inv.y, noi.y), fLy = __builtin_fmaf(ay.y, inv.y, noi.y);
@@ -606,6 +620,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
 #else
                         q0 = q1 = q2 = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
 #endif
+                        const v3 noi = mk(-(p.r.o.x * inv.x), -(p.r.o.y * inv.y), -(p.r.o.z * inv.z));  // CRT_FAST only (dead otherwise)
                         hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, noi, tmin, best_t);
                         hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, noi, tmin, best_t);
                     }
@@ -812,12 +827,12 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const float4 b = make_float4(u01(rr.x), u01(rr.y), u01(rr.z), u01(rr.w));
                         if (q.w == (uint32_t)K_VEC) {
                             v0 = rf11(b.x); v1 = rf11(b.y); v2 = rf11(b.z);
-                            const float l = v0 * v0 + v1 * v1 + v2 * v2;
+                            const float l = lensq3(v0, v1, v2);
                             ok = 0.0f < l && l <= 1.0f;
                         } else {
                             v0 = rf11(b.x); v1 = rf11(b.y);
-                            ok = v0 * v0 + v1 * v1 + 0.0f * 0.0f < 1.0f;
-                            if (!ok) { v0 = rf11(b.z); v1 = rf11(b.w); ok = v0 * v0 + v1 * v1 + 0.0f * 0.0f < 1.0f; }
+                            ok = lensq3(v0, v1, 0.0f) < 1.0f;
+                            if (!ok) { v0 = rf11(b.z); v1 = rf11(b.w); ok = lensq3(v0, v1, 0.0f) < 1.0f; }
                         }
                     }
                     const unsigned long long m_ok = __ballot(ok);
@@ -831,7 +846,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (kind != K_NONE) {
                         if (mine != 0u) {
                             rs.event += first + 1u;
-                            if (kind == K_VEC) { u0 = w0; u1 = w1; u2 = w2; u3 = u0 * u0 + u1 * u1 + u2 * u2; }
+                            if (kind == K_VEC) { u0 = w0; u1 = w1; u2 = w2; u3 = lensq3(u0, u1, u2); }
                             else { dx = w0; dy = w1; }
                             kind = K_NONE;
                         } else {
@@ -842,7 +857,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     const float4 b = rs.next_block();
                     if (kind == K_VEC) {
                         u0 = rf11(b.x); u1 = rf11(b.y); u2 = rf11(b.z);
-                        u3 = u0 * u0 + u1 * u1 + u2 * u2;
+                        u3 = lensq3(u0, u1, u2);
                         if (0.0f < u3 && u3 <= 1.0f) kind = K_NONE;
                     } else if (kind == K_U) {
                         u0 = b.x; kind = K_NONE;
@@ -850,10 +865,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         u0 = b.x - 0.5f; u1 = b.y - 0.5f; u2 = 1.0f - b.z; kind = K_DISK;
                     } else {  // K_DISK: two attempts per block
                         dx = rf11(b.x); dy = rf11(b.y);
-                        if (dx * dx + dy * dy + 0.0f * 0.0f < 1.0f) kind = K_NONE;
+                        if (lensq3(dx, dy, 0.0f) < 1.0f) kind = K_NONE;
                         else {
                             dx = rf11(b.z); dy = rf11(b.w);
-                            if (dx * dx + dy * dy + 0.0f * 0.0f < 1.0f) kind = K_NONE;
+                            if (lensq3(dx, dy, 0.0f) < 1.0f) kind = K_NONE;
                         }
                     }
                 }
@@ -909,9 +924,6 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     } else {
                         inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
                         exact = !finite3(inv);
-#if CRT_FAST
-                        noi = mk(-(p.r.o.x * inv.x), -(p.r.o.y * inv.y), -(p.r.o.z * inv.z));
-#endif
                         if (IN_LDS) {
                             offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
                             offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;

@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_ARITH")
 
 
 def make(variant, args):
