@@ -210,6 +210,11 @@ class Renderer:
                                                      tile_offset, C.c_void_p(d_sums_ptr), C.c_void_p(stream or 0)),
                    "crt_render_accumulate_tiles", self._ctx)
 
+    def render_static(self, world, spp, sample_offset, max_depth, d_fb_ptr, stream=None):
+        """crt_render_static: the frame of crt_render into the caller's device buffer, no allocation."""
+        _check(lib().crt_render_static(self._ctx, world, spp, sample_offset, max_depth, C.c_void_p(d_fb_ptr),
+                                       C.c_void_p(stream or 0)), "crt_render_static", self._ctx)
+
     def resolve(self, d_sums_ptr, spp, d_fb_ptr, stream=None):
         _check(lib().crt_resolve(self._ctx, C.c_void_p(d_sums_ptr), spp, C.c_void_p(d_fb_ptr), C.c_void_p(stream or 0)),
                "crt_resolve", self._ctx)

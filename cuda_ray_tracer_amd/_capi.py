@@ -19,7 +19,7 @@ EXPORTS = [
     "crt_upload_bvh_nodes", "crt_render_accumulate_tiles", "crt_set_arith", "crt_last_kernel_name", "crt_build_id",
     "crt_group_create", "crt_group_destroy", "crt_group_size", "crt_group_member", "crt_group_last_error",
     "crt_group_upload_scene", "crt_group_build_bvh", "crt_group_upload_bvh_nodes", "crt_group_set_camera",
-    "crt_group_render",
+    "crt_group_render", "crt_render_static",
 ]
 
 CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC = 0, 1, 2
@@ -94,6 +94,7 @@ def load(path=LIB_PATH):
     lib.crt_trace_samples.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, ip, C.c_int32, fp, fp, ip]
     lib.crt_upload_bvh_nodes.argtypes = [vp, C.POINTER(BvhNode), C.c_int32]
     lib.crt_render_accumulate_tiles.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    lib.crt_render_static.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.crt_set_arith.argtypes = [vp, C.c_int32]
     lib.crt_last_kernel_name.restype = C.c_char_p
     lib.crt_last_kernel_name.argtypes = [vp]

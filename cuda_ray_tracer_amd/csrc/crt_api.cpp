@@ -38,6 +38,7 @@ struct crt_context {
     unsigned long long* d_sums = nullptr;
     size_t fb_floats = 0;
     unsigned long long* d_counters = nullptr;
+    unsigned long long* d_static = nullptr;  // this GPU's static scratch (crt_static.hip), resolved by the first crt_render_static
     int *d_px = nullptr, *d_py = nullptr, *d_smp = nullptr, *d_seg = nullptr;
     float *d_ray7 = nullptr, *d_rgb = nullptr;
     int dbg_cap = 0;
@@ -482,6 +483,33 @@ int crt_render_accumulate_tiles(crt_context* ctx, int32_t world, int32_t sample_
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
     return launch_accumulate(ctx, world, sample_offset, nsamples, max_depth, tile_stride, tile_offset, d_sums, stream,
                              ctx->d_counters);
+}
+
+int crt_render_static(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
+                      float* d_fb, void* stream_) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!d_fb) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_static: d_fb is NULL");
+    if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "crt_render_static: no camera set");
+    if (spp < 1) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_render_static: spp < 1");
+    const size_t pixels = size_t(ctx->cam.image_width) * size_t(ctx->cam.image_height);
+    if (pixels > size_t(CRT_STATIC_MAX_PIXELS))
+        return fail(ctx, CRT_ERR_TOO_LARGE, "crt_render_static: frame of " + std::to_string(pixels) + " pixels exceeds the static scratch (" +
+                                                std::to_string(CRT_STATIC_MAX_PIXELS) + " pixels); use crt_render / crt_render_accumulate");
+    static_assert(CRT_STATIC_MAX_PIXELS == CRT_STATIC_MAX_PIXELS_, "header and scratch size disagree");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // The address of THIS GPU's copy of the array: resolved on the first call on a device (crt_static.hip caches it
+    // per device).  Resolving it at crt_create would make every context pay for loading the array (17 ms measured for
+    // 48 MiB) whether or not it ever renders this way; like the first launch of any kernel, the first call on a device
+    // loads a code object -- a caller that must not allocate makes one warm-up call before it starts.
+    if (!ctx->d_static) CRT_HIP_TRY(ctx, crt_static_scratch(ctx->device, &ctx->d_static));
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned long long* counters = ctx->d_static;                       // this GPU's array, shared by every call on it
+    unsigned long long* sums = ctx->d_static + CRT_STATIC_COUNTER_WORDS;
+    // the array keeps the last call's contents: the sums of THIS frame must start at zero (the launch clears the counters)
+    CRT_HIP_TRY(ctx, hipMemsetAsync(sums, 0, 3 * pixels * sizeof(unsigned long long), stream));
+    if (int rc = launch_accumulate(ctx, world, sample_offset, spp, max_depth, 1, 0, (int64_t*)sums, stream_, counters)) return rc;
+    CRT_HIP_TRY(ctx, crt_launch_resolve(sums, d_fb, 3 * pixels, spp, stream));  // camera.h:76 scale
+    return CRT_OK;
 }
 
 int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream) {

@@ -193,6 +193,19 @@ int crt_render_accumulate_tiles(crt_context* ctx, int32_t world, int32_t sample_
                                 int32_t max_depth, int32_t tile_stride, int32_t tile_offset, int64_t* d_sums,
                                 void* stream);
 
+/* crt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same image as crt_render, bit for bit, written
+ * as W*H*3 fp32 to the caller's DEVICE buffer d_fb, asynchronously on `stream`.  The work-queue counter, the
+ * statistics and the int64 sums of the frame live in a static per-GPU scratch array inside the library (about 48 MiB,
+ * held by every GPU this entry point has been called on until the process ends) instead of allocated buffers: the
+ * call makes no hipMalloc / hipFree.  As with any kernel, the FIRST call on a GPU makes the runtime load code objects
+ * (the render kernels' and the array's): make one warm-up call before entering a region that must not allocate.  Limit: frames of at most CRT_STATIC_MAX_PIXELS pixels; larger ones are rejected
+ * with CRT_ERR_TOO_LARGE.  All calls on one GPU share that GPU's array -- calls that overlap on one GPU (two streams,
+ * two contexts, two threads) race; order them. */
+#define CRT_STATIC_MAX_PIXELS (1 << 21)
+int crt_render_static(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
+                      float* d_fb, void* stream);
+
 /* cam.pixel_samples_scale (camera.h:76, render_with_cuda.h:164): device buffer of fixed-point
  * sums over `spp` samples -> fp32 frame, fb[i] = (float)((double)d_sums[i] * (2^-40 / spp)). */
 int crt_resolve(crt_context* ctx, const int64_t* d_sums, int32_t spp, float* d_fb, void* stream);
