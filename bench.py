@@ -50,6 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
                     help="N > 1: rank g traces samples [g spp/N, (g+1) spp/N) of every pixel (default, north_star), or "
                          "all samples of the 8x8 tiles t = g mod N")
+    ap.add_argument("--arith", choices=["exact", "fast"], default="exact",
+                    help="arithmetic of the TIMED steps: exact (default; every fp32 operation rounded separately, frames "
+                         "bit-identical to the CPU oracle) or fast (fma slab test + contraction; within the tolerance of "
+                         "tests/test_gpu_round2.py::test_fast_arithmetic_within_stated_tolerance).  The other mode is measured "
+                         "beside it, untimed by the step clock (HIP events)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the RCCL process group and issue every collective of the "
                          "N > 1 path (one-GPU rehearsal, tests/test_gpu_rccl.py)")
@@ -165,6 +170,7 @@ class GpuRank:
         torch.cuda.synchronize()
         self.t_hip = time.perf_counter() - t0
         self.r = crt.Renderer(local_rank, args.seed)
+        self.r.set_arith(crt.CRT_ARITH_FAST if args.arith == "fast" else crt.CRT_ARITH_EXACT)
         self.t_ctx = time.perf_counter() - t0 - self.t_hip   # crt_create: library state on an initialised runtime
         self.scene = crt.scene_small() if args.config == "c1" else crt.scene_random(args.scene_seed, **scene_kw)
         self.t_scene = time.perf_counter() - t0 - self.t_ctx - self.t_hip
@@ -350,7 +356,8 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
     crt, r = g.crt, g.r
     W, H = g.W, g.H
     build = crt.build_info()
-    out["arith"] = build["arith"]
+    build["arith"] = args.arith
+    out["arith"] = args.arith
     out["library_build_id"] = build["build_id"]
     out["config"].update({"spheres": g.scene.n, "bvh_nodes": g.num_nodes})
     kernel = r.kernel_name()  # of the last timed-path launch (the time-to-image step)
@@ -422,6 +429,19 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
                                  "tools/ubench/gather_quad.hip reaches with dependent 64-byte record reads from an "
                                  "L1-resident table and nothing else to do (250-290 G records/s chip-wide)",
                          "record_fetch_Gs": rec_gs, "record_rate_limit_Gs": [250, 290]})
+    if world_size == 1:
+        # the other arithmetic mode on the same workload, beside the timed one (3 launches, HIP events; not `value`)
+        other = "fast" if args.arith == "exact" else "exact"
+        r.set_arith(crt.CRT_ARITH_FAST if other == "fast" else crt.CRT_ARITH_EXACT)
+        for _ in range(4):
+            g.trace(share["first"], share["nsamples"], share["tile_stride"], share["tile_offset"])
+        ost = r.stats()
+        oms = float(np.mean(r.kernel_times(3))) * 1e3
+        r.set_arith(crt.CRT_ARITH_FAST if args.arith == "fast" else crt.CRT_ARITH_EXACT)
+        out["other_arith"] = {"arith": other, "kernel": r.kernel_name(), "kernel_ms": oms, "rays_per_launch": int(ost.rays),
+                              "mrays_s": ost.rays / oms / 1e3,
+                              "contract": "exact: bit-identical to the oracle; fast: >= 99 % of paths keep their segment count, "
+                                          "500-spp frames agree to PSNR >= 45 dB (measured 64 dB), tests/test_gpu_round2.py"}
     if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
         out["cpu_baseline"] = cpu_baseline(args, args.seed)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CRT_ARITH_EXACT, CRT_ARITH_FAST, CRT_DIELECTRIC, CRT_LAMBERTIAN, CRT_METAL, CRT_SPLIT_SAMPLES,
+from ._capi import (CRT_ARITH_EXACT, CRT_ARITH_FAST, CRT_DIELECTRIC, CRT_LAMBERTIAN, CRT_MATERIAL_BASE, CRT_METAL, CRT_SPLIT_SAMPLES,
                     CRT_SPLIT_TILES, CRT_WORLD_BVH, CRT_WORLD_LIST, BvhNode, Camera, CameraParams, RenderStats)
 
 __all__ = ["lib", "Scene", "camera", "reference_camera", "scene_small", "scene_random", "bvh_build_host",

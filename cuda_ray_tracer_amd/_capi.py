@@ -22,7 +22,7 @@ EXPORTS = [
     "crt_group_render", "crt_render_static",
 ]
 
-CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC = 0, 1, 2
+CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC, CRT_MATERIAL_BASE = 0, 1, 2, 3
 CRT_WORLD_LIST, CRT_WORLD_BVH = 0, 1
 CRT_ARITH_EXACT, CRT_ARITH_FAST = 0, 1
 CRT_SPLIT_SAMPLES, CRT_SPLIT_TILES = 0, 1

@@ -220,7 +220,7 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
         return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: empty scene or NULL array");
     if (m > CRT_MAT_ID_MASK) return fail(ctx, CRT_ERR_TOO_LARGE, "crt_upload_scene: too many materials");
     for (int i = 0; i < m; ++i)
-        if (mat_type[i] < 0 || mat_type[i] > 2) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: unknown material type");
+        if (mat_type[i] < 0 || mat_type[i] > CRT_MATERIAL_BASE) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: unknown material type");
     for (int i = 0; i < n; ++i)
         if (mat_id[i] < 0 || mat_id[i] >= m) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_upload_scene: mat_id out of range");
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -41,9 +41,8 @@ struct crt_flat_material {
 class material {  // material.h:7-20
   public:
     virtual ~material() = default;
-    // a material of the base class never scatters (material.h:11-19): the path returns black.
-    // It flattens to a lambertian of albedo 0, whose paths carry zero radiance as well.
-    virtual crt_flat_material flatten() const { return {CRT_LAMBERTIAN, color(0, 0, 0), 0.0f}; }
+    // a material of the base class never scatters (material.h:11-19): the path returns black at once
+    virtual crt_flat_material flatten() const { return {CRT_MATERIAL_BASE, color(0, 0, 0), 0.0f}; }
 };
 
 class lambertian : public material {  // material.h:22-42

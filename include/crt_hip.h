@@ -31,10 +31,11 @@ extern "C" {
 #define CRT_ERR_STATE 4
 #define CRT_ERR_TOO_LARGE 5
 
-/* material.h:22-98 -- the three subclasses, flattened to a tag */
+/* material.h:7-98 -- the class hierarchy, flattened to a tag */
 #define CRT_LAMBERTIAN 0
 #define CRT_METAL 1
 #define CRT_DIELECTRIC 2
+#define CRT_MATERIAL_BASE 3 /* material.h:11-19: the base class, scatter() returns false -- the path ends black */
 
 /* arithmetic of the render kernels (crt_set_arith) */
 #define CRT_ARITH_EXACT 0 /* every fp32 operation rounded separately, in the order of the reference's C++ expressions:

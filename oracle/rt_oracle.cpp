@@ -234,7 +234,7 @@ struct aabb {
 };
 
 // ---------------------------------------------------------------------------------------
-// material.h (flattened: type 0 lambertian :22-42, 1 metal :44-60, 2 dielectric :62-98)
+// material.h (flattened: type 0 lambertian :22-42, 1 metal :44-60, 2 dielectric :62-98, 3 the base class :11-19)
 struct material {
     int type;
     color albedo;
@@ -381,6 +381,7 @@ inline float reflectance(float cosine, float refraction_index) {
 
 bool scatter(const material& m, sample_stream& rs, const ray& r_in, const hit_record& rec,
              color& attenuation, ray& scattered) {
+    if (m.type == 3) return false;  // material::scatter of the base class, material.h:11-19: never scatters, no draw
     if (m.type == 0) {  // material.h:26-38
         auto scatter_direction = rec.normal + random_unit_vector(rs);
         if (scatter_direction.near_zero()) scatter_direction = rec.normal;

@@ -52,6 +52,8 @@ int main() {
     CHECK(cam.get_center().x() == 13 && cam.get_center().y() == 2);
     sphere moving(point3(0, 0, 0), point3(0, 0.5f, 0), 0.2f, nullptr), copy(moving);
     CHECK(copy.bounding_box().y.max == 0.7f && copy.bounding_box().y.min == -0.2f);
+    material base;  // material.h:11-19: never scatters
+    CHECK(base.flatten().type == CRT_MATERIAL_BASE);
     metal m(color(1, 1, 1), 3.0f);
     CHECK(m.flatten().param == 1.0f);  // fuzz clamp, material.h:46
     // shared material pointers flatten to one material

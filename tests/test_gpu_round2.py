@@ -315,6 +315,38 @@ def test_glass_of_index_one_lets_rays_straight_through(crt, world):
     r.close()
 
 
+@pytest.mark.parametrize("world", ["bvh", "list"])
+def test_base_class_material_ends_the_path_black(crt, orc, world):
+    """material.h:11-19: `material::scatter` of the base class returns false, so ray_color returns black at that hit
+    (render_with_cuda.h:43-46) without drawing a random number.  Bit-exact against the oracle, and the analytic
+    property: a primary ray whose first hit is such a sphere has exactly 1 segment and zero radiance."""
+    sc = crt.scene_random(18, 5)
+    mt = sc.mat_type.copy()
+    mt[::3] = crt.CRT_MATERIAL_BASE
+    mt[0] = crt.CRT_LAMBERTIAN  # keep the ground
+    sc = crt.Scene(sc.center, sc.motion, sc.radius, sc.mat_id, mt, sc.mat_albedo, sc.mat_param)
+    osc = orc.Scene(sc.center, sc.motion, sc.radius, sc.mat_id, mt, sc.mat_albedo, sc.mat_param)
+    nodes = orc.bvh_build(osc, 17)[0] if world == "bvh" else None
+    cam, ocam = crt.camera(160, 6), orc.camera(160, 6)
+    r = _renderer(crt, sc, cam, 8, bvh=world == "bvh")
+    wk = crt.CRT_WORLD_BVH if world == "bvh" else crt.CRT_WORLD_LIST
+    fb, st = r.render(wk, 6, 0, 50)
+    sums, ost = orc.render(osc, ocam, 8, 0, 6, 50, nodes, nthreads=8)
+    assert _bits_equal(fb, orc.resolve(sums, 6)) and st.rays == ost[0]
+    rng = np.random.default_rng(3)
+    n = 4000
+    px, py, smp = rng.integers(0, 160, n), rng.integers(0, 90, n), rng.integers(0, 6, n)
+    ray7, rgb, seg = r.trace_samples(wk, px, py, smp, 50)
+    hits = 0
+    for i in range(0, n, 7):
+        obj, _ = orc.closest_hit(osc, ray7[i], nodes)
+        if obj >= 0 and mt[sc.mat_id[obj]] == crt.CRT_MATERIAL_BASE:
+            hits += 1
+            assert seg[i] == 1 and (rgb[i] == 0).all()
+    assert hits > 10
+    r.close()
+
+
 # ---- contracted arithmetic ------------------------------------------------------------------------------
 
 def test_fast_arithmetic_within_stated_tolerance(crt):
