@@ -395,7 +395,7 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
     # build (hash of the kernel sources) and the kernel it was taken at: any other build or kernel reports null.
     try:
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        pmc = pmc_all[args.config]
+        pmc = pmc_all[args.config + ("_fast" if args.arith == "fast" else "")]
         same = (pmc.get("build_id") == build["build_id"] and pmc.get("kernel") == kernel and pmc.get("width") == W
                 and pmc.get("spp") == args.spp and world_size == 1)
         if same:
