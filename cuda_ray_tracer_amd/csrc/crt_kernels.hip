@@ -58,10 +58,21 @@ __device__ __forceinline__ float len2(v3 a) { return sum3(a.x * a.x, a.y, a.z); 
 __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float len2(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 #endif
+// reciprocal, square root, reciprocal square root: correctly rounded in the exact build (the reference's 1/x, sqrtf);
+// the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 in the fast build (one instruction instead of the ~10 of the
+// correctly rounded sequences)
+#if CRT_FAST
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+__device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+#endif
+__device__ __forceinline__ v3 unit(v3 a) { return rsqrt_(len2(a)) * a; }  // vec3.h:114-116,130-132: v / t == (1/t) * v
 // squared length of a rejection-sampling attempt (vec3.h:147-149,156-158: x*x + y*y + z*z, z = 0 for the disk)
 __device__ __forceinline__ float lensq3(float x, float y, float z) { return len2(mk(x, y, z)); }
-// vec3.h:114-116,130-132: v / t == (1/t) * v
-__device__ __forceinline__ v3 unit(v3 a) { return (1.0f / sqrtf(len2(a))) * a; }
 
 // ---- Philox4x32-10, counter = (event, sample, pixel, 0), key = seed -------------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -100,7 +111,7 @@ __device__ __forceinline__ v3 random_unit_vector(stream& rs) {
         const float4 b = rs.next_block();
         const v3 p = mk(rf11(b.x), rf11(b.y), rf11(b.z));
         const float lensq = len2(p);
-        if (0.0f < lensq && lensq <= 1.0f) return (1.0f / sqrtf(lensq)) * p;
+        if (0.0f < lensq && lensq <= 1.0f) return rsqrt_(lensq) * p;
     }
 }
 
@@ -170,13 +181,23 @@ __device__ __forceinline__ float sphere_root(const sphere_rec& s, const ray_t& r
     const float c = len2(oc) - s.radius * s.radius;
     const float disc = h * h - a * c;
     if (disc < 0.0f) return -1.0f;
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_(disc);
+#if CRT_FAST
+    const float ia = rcp_(a);
+    float root = (h - sq) * ia;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sq) * ia;
+        if (!(tmin < root && root < tmax)) return -1.0f;
+    }
+    return root;
+#else
     float root = (h - sq) / a;
     if (!(tmin < root && root < tmax)) {
         root = (h + sq) / a;
         if (!(tmin < root && root < tmax)) return -1.0f;
     }
     return root;
+#endif
 }
 
 // aabb.h:48-62 for one box (the :41-46 guard is not reproduced)
@@ -253,7 +274,7 @@ __device__ __forceinline__ hit_t closest_hit_bvh(const float4* pairs, const floa
         if (root > 0.0f) { best.t = root; best.obj = __float_as_int(pairs[3].x); }
         return best;
     }
-    const v3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);  // aabb.h:48
+    const v3 inv = mk(rcp_(r.d.x), rcp_(r.d.y), rcp_(r.d.z));  // aabb.h:48
     const uint32_t leaf_parents = (uint32_t)num_leaves >> 1;
     uint32_t k = 1, pending = 0;
     for (;;) {
@@ -320,7 +341,7 @@ __device__ __forceinline__ bool shade(path_t& p, stream& rs, const sphere_rec& s
     // sphere.h:66-70, hittable.h:16-22
     const v3 pos = p.r.o + t * p.r.d;
     const v3 cc = s.c + p.r.tm * s.mo;
-    const v3 outward = (1.0f / s.radius) * (pos - cc);
+    const v3 outward = rcp_(s.radius) * (pos - cc);
     const bool front = dot(p.r.d, outward) < 0.0f;
     const v3 nrm = front ? outward : -outward;
     const int type = (uint32_t)s.mat >> CRT_MAT_TYPE_SHIFT;
@@ -341,7 +362,7 @@ __device__ __forceinline__ bool shade(path_t& p, stream& rs, const sphere_rec& s
         const float ri = front ? mrec.y : mrec.x;
         const v3 ud = unit(p.r.d);
         const float cos_theta = fminf(dot(-ud, nrm), 1.0f);
-        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const float sin_theta = sqrt_(1.0f - cos_theta * cos_theta);
         bool do_reflect = ri * sin_theta > 1.0f;
         if (!do_reflect) do_reflect = reflectance(cos_theta, ri) > (1.0f - rs.next_block().x);
         v3 dir;
@@ -349,7 +370,7 @@ __device__ __forceinline__ bool shade(path_t& p, stream& rs, const sphere_rec& s
             dir = ud - (2.0f * dot(ud, nrm)) * nrm;
         } else {  // refract, vec3.h:138-143
             const v3 perp = ri * (ud + cos_theta * nrm);
-            const v3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * nrm;
+            const v3 par = (-sqrt_(fabsf(1.0f - len2(perp)))) * nrm;
             dir = perp + par;
         }
         p.r.o = pos; p.r.d = dir;  // attenuation (1,1,1): thr * 1 == thr
@@ -707,7 +728,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const float4 mrec = mats[sp.mat & CRT_MAT_ID_MASK];
                         const v3 pos = p.r.o + best_t * p.r.d;
                         const v3 cc = sp.c + p.r.tm * sp.mo;
-                        const v3 outward = (1.0f / sp.radius) * (pos - cc);
+                        const v3 outward = rcp_(sp.radius) * (pos - cc);
                         const bool front = dot(p.r.d, outward) < 0.0f;
                         nrm = front ? outward : -outward;
                         type = (int)((uint32_t)sp.mat >> CRT_MAT_TYPE_SHIFT);
@@ -724,7 +745,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                             aux = front ? mrec.y : mrec.x;
                             base = unit(p.r.d);
                             scale = fminf(dot(-base, nrm), 1.0f);
-                            const float sin_theta = sqrtf(1.0f - scale * scale);
+                            const float sin_theta = sqrt_(1.0f - scale * scale);
                             cannot = aux * sin_theta > 1.0f;
                             kind = cannot ? K_NONE : K_U;  // the draw is short-circuited away under TIR
                         }
@@ -902,7 +923,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (type == 3) {
                         dir = p.r.d; absorbed = true;
                     } else if (type <= 1) {
-                        const v3 ruv = (1.0f / sqrtf(u3)) * mk(u0, u1, u2);
+                        const v3 ruv = rsqrt_(u3) * mk(u0, u1, u2);
                         dir = base + scale * ruv;
                         if (type == 0) {  // vec3.h:62-66 near_zero (double threshold)
                             if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = nrm;
@@ -916,7 +937,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                             dir = base - (2.0f * dot(base, nrm)) * nrm;
                         } else {  // refract, vec3.h:138-143
                             const v3 perp = aux * (base + scale * nrm);
-                            const v3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * nrm;
+                            const v3 par = (-sqrt_(fabsf(1.0f - len2(perp)))) * nrm;
                             dir = perp + par;
                         }
                     }
@@ -944,7 +965,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (NL == 1u) {
                         // the root is the only leaf (k >= NL: sphere phase next): no box is tested
                     } else {
-                        inv = mk(1.0f / p.r.d.x, 1.0f / p.r.d.y, 1.0f / p.r.d.z);  // aabb.h:48
+                        inv = mk(rcp_(p.r.d.x), rcp_(p.r.d.y), rcp_(p.r.d.z));  // aabb.h:48
                         exact = !finite3(inv);
                         if (IN_LDS) {
                             offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;

@@ -40,9 +40,9 @@ extern "C" {
 /* arithmetic of the render kernels (crt_set_arith) */
 #define CRT_ARITH_EXACT 0 /* every fp32 operation rounded separately, in the order of the reference's C++ expressions:
                              a path is bit-identical to the CPU oracle (the parity suite's mode; default) */
-#define CRT_ARITH_FAST 1  /* the slab test contracted to fused multiply-adds, t = fma(plane, 1/d, -o/d): what nvcc's
-                             default -fmad=true does to aabb.h:48-62; images agree with EXACT within the tolerance
-                             stated in DESIGN.md, not bit for bit */
+#define CRT_ARITH_FAST 1  /* tolerance mode: the slab test of aabb.h:48-62 as one fma per plane, t = fma(plane, 1/d, -o/d), fp
+                             contraction, 1-ulp hardware rcp / sqrt / rsq; images agree with EXACT within the tolerance
+                             stated in DESIGN.md (PSNR >= 45 dB at 500 spp), not bit for bit; +16 % rays/s */
 
 /* how crt_group_render cuts one image over the group's devices */
 #define CRT_SPLIT_SAMPLES 0 /* member g traces samples [g spp/G, (g+1) spp/G) of every pixel (north_star) */
