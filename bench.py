@@ -16,6 +16,7 @@ Metric: Mrays/s, whole job; one ray = one closest-hit query of the bounce loop
       --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -58,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the RCCL process group and issue every collective of the "
                          "N > 1 path (one-GPU rehearsal, tests/test_gpu_rccl.py)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="one-GPU rehearsal of the N-rank HIP path (tests/test_gpu_rccl.py): every rank renders its share on "
+                         "GPU 0 with the real kernels, the int64 frames are reduced through host copies over gloo (RCCL "
+                         "refuses two ranks on one device); a correctness rehearsal, its timings mean nothing")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="control-flow rehearsal without a GPU (tests/test_bench_launcher.py): gloo ranks, CPU tensors and "
                          "a stand-in tracer that adds 2^40 per sample; prints a line marked \"data\": \"rehearsal\"")
@@ -158,6 +163,8 @@ class GpuRank:
         import cuda_ray_tracer_amd as crt
         self.torch, self.crt = torch, crt
         n_dev = torch.cuda.device_count()  # does not initialise the GPU on this image
+        if args.share_gpu:
+            local_rank = 0
         if local_rank >= n_dev:
             raise SystemExit(f"bench.py: {args.gpus} devices requested, {n_dev} visible (rank {local_rank} has no GPU)")
         torch.cuda.set_device(local_rank)
@@ -187,7 +194,7 @@ class GpuRank:
         self.frame = torch.empty(self.H, self.W, 3, dtype=torch.float32, device=self.dev)
         self.stream = torch.cuda.current_stream().cuda_stream
         self.depth = args.depth
-        self.backend = "nccl"
+        self.backend = "gloo" if args.share_gpu else "nccl"
 
     def trace(self, first, count, tile_stride=1, tile_offset=0):
         self.r.render_accumulate(self.world, first, count, self.depth, self.sums.data_ptr(), self.stream,
@@ -265,7 +272,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        kw = {} if args.rehearse_cpu else {"device_id": g.dev}
+        kw = {} if (args.rehearse_cpu or args.share_gpu) else {"device_id": g.dev}
         dist.init_process_group(g.backend, rank=rank, world_size=world_size, **kw)
     W, H = g.W, g.H
 
@@ -274,7 +281,8 @@ def main():
     has_work = share["nsamples"] > 0
 
     def step():  # zero, trace this rank's share, RCCL reduce(SUM) to rank 0, resolve to fp32 there.  EVERY rank calls it.
-        render_split(g.trace, g.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split)
+        render_split(g.trace, g.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split,
+                     host_staged=args.share_gpu)
         if rank == 0:
             g.resolve(args.spp)
 
@@ -306,7 +314,7 @@ def main():
         if has_work and args.steps > 0:
             kernel_s = g.r.kernel_times(min(args.steps, 64))
 
-    t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device=g.dev)
+    t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device="cpu" if args.share_gpu else g.dev)
     if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -341,6 +349,7 @@ def main():
             "time_to_image_ms": t_image * 1e3, "setup_ms": g.t_setup * 1e3,
             "hip_runtime_init_ms": g.t_hip * 1e3, "context_ms": g.t_ctx * 1e3, "scene_generation_ms": g.t_scene * 1e3, "bvh_build_ms": g.t_bvh * 1e3,
             "image_mean": float(img.mean()),
+            "frame_sha256": hashlib.sha256(img.numpy().tobytes()).hexdigest(),
         }
         if not args.rehearse_cpu:
             gpu_report(args, g, out, share, kernel_s, world_size, np)

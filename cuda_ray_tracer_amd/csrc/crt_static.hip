@@ -11,6 +11,8 @@
 //   [CRT_STATIC_COUNTER_WORDS, + 3 * MAX_PIXELS)   int64 2^-40 fixed-point RGB sums of the frame
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "crt_launch.h"
 
 static __device__ __align__(256) unsigned long long scratch[CRT_STATIC_COUNTER_WORDS + 3ull * CRT_STATIC_MAX_PIXELS_];
@@ -18,6 +20,7 @@ static __device__ __align__(256) unsigned long long scratch[CRT_STATIC_COUNTER_W
 namespace {
 constexpr int MAX_DEVICES = 64;
 unsigned long long* g_ptr[MAX_DEVICES] = {};  // per device: the address of ITS copy of `scratch`
+std::mutex g_mutex;                            // contexts of several host threads may make their first call at once
 }
 
 // The device pointer of `device`'s scratch array.  First call per device (the first crt_render_static on it makes it):
@@ -25,6 +28,7 @@ unsigned long long* g_ptr[MAX_DEVICES] = {};  // per device: the address of ITS 
 // the array -- on that GPU.
 hipError_t crt_static_scratch(int device, unsigned long long** out) {
     if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_mutex);
     if (!g_ptr[device]) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return e;

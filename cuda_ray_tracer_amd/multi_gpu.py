@@ -30,7 +30,19 @@ def resolve(sums, spp):
     return (sums.to(torch.float64) * (2.0 ** -40 / spp)).to(torch.float32)
 
 
-def render_split(trace_range, sums, spp, world_size, rank, always_reduce=False, split="samples"):
+def reduce_sums(sums, host_staged=False):
+    """reduce(SUM) of the int64 frame to rank 0.  host_staged: through a host copy -- the one-GPU rehearsal where several
+    ranks share a device (RCCL refuses two ranks on one GPU) and the process group is gloo."""
+    if not host_staged:
+        dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+        return
+    host = sums.cpu()
+    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+    if dist.get_rank() == 0:
+        sums.copy_(host)
+
+
+def render_split(trace_range, sums, spp, world_size, rank, always_reduce=False, split="samples", host_staged=False):
     """One image: zero `sums`, trace this rank's share into it with `trace_range(first, n, tile_stride, tile_offset)`
     (the arguments of crt_render_accumulate_tiles; the callback adds to `sums`), reduce to rank 0.  `sums` is a (H, W, 3) int64 tensor on the rank's device; after the call rank
     0 holds the sums of all `spp` samples (resolve them with crt_resolve / resolve()).
@@ -41,5 +53,5 @@ def render_split(trace_range, sums, spp, world_size, rank, always_reduce=False, 
     if sh["nsamples"] > 0:
         trace_range(sh["first"], sh["nsamples"], sh["tile_stride"], sh["tile_offset"])
     if world_size > 1 or always_reduce:
-        dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+        reduce_sums(sums, host_staged)
     return sums

@@ -29,3 +29,28 @@ def test_bench_step_through_rccl_group_of_one():
     assert a["rays_per_step"] == b["rays_per_step"] > 0
     assert a["image_mean"] == b["image_mean"]
     assert b["n_gpus"] == 1 and b["value"] > 0
+
+
+@pytest.mark.gpu
+def test_hip_path_under_n_ranks_on_one_gpu():
+    """The N-rank path with the REAL kernels in every rank (BASELINE.json configs[2], as far as one GPU allows):
+    `python bench.py --gpus N --share-gpu` starts its own N ranks, all on GPU 0; each traces its share through the C
+    ABI, the int64 frames are reduced over gloo through host copies (RCCL refuses two ranks on one device).  The frame
+    must be the single-rank frame bit for bit (SHA-256 of the fp32 frame) and the rays must add up, for both splits."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--width", "320", "--spp", "9",
+              "--cpu-seconds", "0"]
+
+    def run(extra):
+        r = subprocess.run(common + extra, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--share-gpu"])
+    three = run(["--gpus", "3", "--share-gpu", "--split", "tiles"])
+    assert two["n_gpus"] == 2 and three["n_gpus"] == 3
+    for other in (two, three):
+        assert other["frame_sha256"] == one["frame_sha256"]
+        assert other["rays_per_step"] == one["rays_per_step"] > 0
+        assert other["msamples_per_s"] > 0
