@@ -282,6 +282,57 @@ def test_mirror_reflects_about_the_normal(crt, world):
 
 
 @pytest.mark.parametrize("world", ["bvh", "list"])
+def test_moving_absorber_and_single_bounce_albedo(crt, world):
+    """Two more closed forms.  (a) sphere.h:17-25,46: a MOVING sphere's centre at the ray's time is center1 + time *
+    (center2 - center1); with the base-class material (never scatters) a primary ray is black with 1 segment exactly
+    when the float64 intersection with the sphere AT THAT RAY'S TIME exists -- the static sphere at either end of the
+    motion would classify thousands of rays differently.  (b) material.h:26-38 + render_with_cuda.h:47,49-52: a convex
+    lambertian sphere of albedo A is left after ONE bounce, so every path that hits it first returns exactly
+    A * sky(primary ray), one fp32 product per channel."""
+    c1, motion, rad = np.array([0.0, 0.0, 0.0]), np.array([0.0, 1.5, 0.0]), 0.8
+    lam_c, lam_r, albedo = np.array([0.0, 0.3, 2.4]), 1.0, np.array([0.3, 0.5, 0.7], np.float32)
+    sc = crt.Scene([c1, lam_c], [motion, np.zeros(3)], [rad, lam_r], [0, 1], [crt.CRT_MATERIAL_BASE, crt.CRT_LAMBERTIAN],
+                   [[0, 0, 0], albedo], [0.0, 0.0])
+    cam = crt.camera(320, 16, vfov=22.0, lookfrom=(7, 0.7, 1.2), lookat=(0, 0.6, 1.2), defocus_angle=0.0, focus_dist=7.0)
+    r = _renderer(crt, sc, cam, 12, bvh=world == "bvh")
+    rng = np.random.default_rng(4)
+    n = 40000
+    px, py, smp = rng.integers(0, 320, n), rng.integers(0, 180, n), rng.integers(0, 16, n)
+    ray7, rgb, seg = r.trace_samples(crt.CRT_WORLD_BVH if world == "bvh" else crt.CRT_WORLD_LIST, px, py, smp, 50)
+    o, d, tm = ray7[:, 0:3].astype(np.float64), ray7[:, 3:6].astype(np.float64), ray7[:, 6].astype(np.float64)
+    dn = d / np.linalg.norm(d, axis=1)[:, None]
+
+    def hit_at(centers, radius):
+        oc = centers - o
+        h = (dn * oc).sum(1)
+        disc = h * h - ((oc * oc).sum(1) - radius * radius)
+        t = h - np.sqrt(np.maximum(disc, 0))
+        return np.where((disc >= 0) & (t > 1e-3), t, np.nan), disc
+
+    t_mov, margin = hit_at(c1 + tm[:, None] * motion, rad)
+    t_lam, margin_l = hit_at(np.tile(lam_c, (n, 1)), lam_r)
+    first_mov = ~np.isnan(t_mov) & (np.isnan(t_lam) | (t_mov < t_lam))
+    first_lam = ~np.isnan(t_lam) & ~first_mov
+    sure = (np.abs(margin) > 1e-4) & (np.abs(margin_l) > 1e-4)
+    black = (rgb == 0).all(axis=1)
+    assert first_mov.sum() > 3000 and first_lam.sum() > 3000
+    # (a path that hits the lambertian sphere first can still end on the absorber after its bounce: black, 2 segments)
+    assert np.array_equal((black & (seg == 1))[sure], first_mov[sure])
+    # the time really matters: the sphere frozen at time 0 would classify many of these rays differently
+    t_static, _ = hit_at(np.tile(c1, (n, 1)), rad)
+    assert (np.isnan(t_static) != np.isnan(t_mov)).sum() > 2000
+    sky = _sky_of_primary(ray7)
+    lam = sure & first_lam
+    # convex: the scattered ray leaves (to the sky or onto the absorber) -- except the rare grazing direction that
+    # re-hits the sphere beyond t = 0.001 within fp32 rounding (the reference's own acne, sphere.h:59-64)
+    assert (seg[lam] == 2).mean() > 0.99 and (seg[lam] >= 2).all()
+    lit = lam & ~black & (seg == 2)
+    assert lit.sum() > 3000
+    assert _bits_equal(rgb[lit], (albedo[None, :] * sky[lit]).astype(np.float32))
+    r.close()
+
+
+@pytest.mark.parametrize("world", ["bvh", "list"])
 def test_glass_of_index_one_lets_rays_straight_through(crt, world):
     """dielectric, refraction_index 1.0 (material.h:69-81, vec3.h:138-143): ri = 1, r0 = 0; at near-normal incidence
     Schlick's reflectance (1-cos)^5 is < 1e-5, so the ray refracts, and with ri = 1 refraction leaves its direction
