@@ -449,6 +449,8 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
         r.set_arith(crt.CRT_ARITH_FAST if args.arith == "fast" else crt.CRT_ARITH_EXACT)
         out["other_arith"] = {"arith": other, "kernel": r.kernel_name(), "kernel_ms": oms, "rays_per_launch": int(ost.rays),
                               "mrays_s": ost.rays / oms / 1e3,
+                              "achieved_TFLOPs": flops_per_ray * ost.rays / (oms * 1e-3) / 1e12,  # same algorithmic flops per ray
+                              "roofline_frac": flops_per_ray * ost.rays / (oms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
                               "contract": "exact: bit-identical to the oracle; fast: >= 99 % of paths keep their segment count, "
                                           "500-spp frames agree to PSNR >= 45 dB (measured 64 dB), tests/test_gpu_round2.py"}
     if world_size == 1 and args.cpu_seconds > 0 and args.config == "c2":
