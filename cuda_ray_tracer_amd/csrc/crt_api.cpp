@@ -401,7 +401,7 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
     // a scene that stays in HBM still gets the first pair records (the upper tree levels) in LDS
     int top_pairs = 0;
     if (scheduled && ctx->persist && !in_lds && ctx->top_pairs_max > 0) { top_pairs = 1; while (2 * top_pairs <= ctx->top_pairs_max && size_t(2 * top_pairs) <= L) top_pairs *= 2; }
-    // workgroup size: 24 waves per CU (6 per SIMD at the kernel's 75 VGPRs) from as many workgroups as
+    // workgroup size: 24 waves per CU (6 per SIMD: the kernel stays within 80 VGPRs, 77 in the round-2 build) from as many workgroups as
     // the 160 KB of LDS hold
     int block = ctx->block;
     if (block == 0) {
@@ -425,7 +425,7 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
         // wave pulling (tile, sample chunk) units; coarse units sized for about 16 per wave, 8..32 samples each
         lds += size_t(nw) * 260 * 8;  // per wave: one tile of accumulators, its unit state, 32 block requests
         int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
-        const int by_waves = 24 / nw;  // 6 waves per SIMD at the kernel's 75 VGPRs
+        const int by_waves = 24 / nw;  // 6 waves per SIMD: the kernel stays within 80 VGPRs
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
         const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * nw;
