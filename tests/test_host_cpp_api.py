@@ -23,6 +23,15 @@ def test_host_classes_flatten_and_bvh(tmp_path, crt):
     assert r.stdout.strip().endswith("OK")
 
 
+def test_header_is_plain_c_and_host_entry_points_work(tmp_path, crt):
+    """include/crt_hip.h through a C99 compiler (what a cgo / JNI / N-API binding would see), linked against the library."""
+    exe = str(tmp_path / "c_abi_check")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
+                    f"-L{PKG}", "-lcrt_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", (r.returncode, r.stdout, r.stderr)
+
+
 def test_cli_builds_and_rejects_unknown_arguments(crt):
     subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-s", "../rt_main"], check=True)
     exe = os.path.join(PKG, "rt_main")
