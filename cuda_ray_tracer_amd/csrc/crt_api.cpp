@@ -152,12 +152,12 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     if (const char* b = getenv("CRT_UNIT_FINE_PCT")) { int v = atoi(b); if (v >= 0 && v <= 100) ctx->fine_pct = v; }
     if (const char* b = getenv("CRT_ARITH")) ctx->arith = strcmp(b, "fast") == 0 ? CRT_ARITH_FAST : CRT_ARITH_EXACT;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counters, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_counters, CRT_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device allocation failed");
     }
     lap("hipMalloc(counters)");
-    if (hipMemset(ctx->d_counters, 0, (32 + 3 * 8192) * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMemset(ctx->d_counters, 0, CRT_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipFree(ctx->d_counters);
         delete ctx;
         return fail(nullptr, CRT_ERR_HIP, "crt_create: device memset failed");
@@ -451,11 +451,20 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
         const int64_t wgs = (units + nw - 1) / nw;
         grid = int(wgs < int64_t(ctx->num_cus) * per_cu ? wgs : int64_t(ctx->num_cus) * per_cu);
     } else {
-        const int tiles_per_group = scheduled ? a.tiles_per_wg : nw;
-        grid = int((tiles + tiles_per_group - 1) / tiles_per_group);
+        // simple loop: one wave per (tile, sample chunk); enough chunks that a small frame still fills the chip
+        if (!scheduled) {
+            const int64_t want_waves = int64_t(ctx->num_cus) * 64;
+            int64_t chunks = tiles > 0 ? (want_waves + tiles - 1) / tiles : 1;
+            chunks = chunks < 1 ? 1 : (chunks > ns_ ? ns_ : chunks);
+            if (const char* b = getenv("CRT_SIMPLE_CHUNKS")) { const int v = atoi(b); if (v >= 1) chunks = v < ns_ ? v : ns_; }
+            a.simple_chunks = int(chunks);
+        }
+        const int64_t groups = scheduled ? (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg : (tiles * a.simple_chunks + nw - 1) / nw;
+        if (groups > (1ll << 31) - 1) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^31-1 workgroups (split the sample range)");
+        grid = int(groups);
         if (scheduled) lds += size_t(a.tiles_per_wg) * (192 * 8 + 8) + 16;  // accumulators, tile origins, item counter
     }
-    CRT_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 32 * sizeof(unsigned long long), stream));
+    CRT_HIP_TRY(ctx, hipMemsetAsync(counters, 0, CRT_TIMELINE_BASE * sizeof(unsigned long long), stream));  // census + striped statistics
     const int slot = int(ctx->launches % crt_context::EV_RING);
     const bool fast = ctx->arith == CRT_ARITH_FAST;
     CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
@@ -530,8 +539,10 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
     float ms = 0;
     CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
-    unsigned long long c[4];
-    CRT_HIP_TRY(ctx, hipMemcpy(c, ctx->last_counters, sizeof c, hipMemcpyDeviceToHost));
+    unsigned long long stripes[4 * CRT_STAT_STRIPES], c[4] = {0, 0, 0, 0};
+    CRT_HIP_TRY(ctx, hipMemcpy(stripes, ctx->last_counters + CRT_STATS_BASE, sizeof stripes, hipMemcpyDeviceToHost));
+    for (int i = 0; i < CRT_STAT_STRIPES; ++i)
+        for (int j = 0; j < 4; ++j) c[j] += stripes[4 * i + j];
     stats->kernel_seconds = ms * 1e-3;
     stats->wall_seconds = ctx->wall_seconds;
     stats->rays = c[0]; stats->samples = c[1]; stats->pair_visits = c[2]; stats->sphere_tests = c[3];
@@ -568,7 +579,7 @@ int crt_debug_timeline(crt_context* ctx, uint64_t* out, int32_t waves) {
     if (!ctx || !out || waves < 1 || waves > 8192) return CRT_ERR_INVALID_ARGUMENT;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
-    CRT_HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters + 32, size_t(waves) * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters + CRT_TIMELINE_BASE, size_t(waves) * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -34,6 +34,17 @@
 #define CRT_SCHED_SPHERES_IN_LDS 0
 #endif
 
+// counter buffer of a launch (unsigned long long words):
+//   [0, 32)                            census, work-queue counter [15], phase cycles, timeline sums (crt_render_args::counters)
+//   [CRT_STATS_BASE, + 4 * STRIPES)    rays, samples, pair visits, sphere tests -- striped over 64 slots by workgroup: every
+//                                      wave adds its totals once, and thousands of atomics on ONE address serialise in L2
+//                                      (10 ns each: 0.28 ms for the 28 000 of a small frame's launch)
+//   [CRT_TIMELINE_BASE, + 3 * 8192)    (start, queue empty, exit) of the first 8192 waves (census only)
+#define CRT_STAT_STRIPES 64
+#define CRT_STATS_BASE 32
+#define CRT_TIMELINE_BASE (CRT_STATS_BASE + 4 * CRT_STAT_STRIPES)
+#define CRT_COUNTER_WORDS (CRT_TIMELINE_BASE + 3 * 8192)
+
 struct crt_dev_camera {
     float center[3], p00[3], du[3], dv[3], ddu[3], ddv[3];
     float defocus_angle;
@@ -55,6 +66,7 @@ struct crt_render_args {
     // tile share of this launch (multi-GPU tile split): it traces the 8x8 tiles t = tile_offset + j * tile_stride,
     // j in [0, n_tiles); the whole frame is stride 1, offset 0, n_tiles = tiles_x * tiles_y
     int tile_stride, tile_offset, n_tiles;
+    int simple_chunks;       // simple loop (list world, SCHED=0): a tile's ns samples are cut into this many chunks, one wave each
     int max_depth;
     int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
     int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
@@ -75,7 +87,7 @@ struct crt_render_args {
     int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
-    unsigned long long* counters;  // [0] rays [1] samples [2] pair visits [3] sphere tests [4..14] census [15] next unit [16..21] phase cycles [22..28] timeline census; [32 + 3 w ...] (start, queue empty, exit) of wave w < 8192
+    unsigned long long* counters;  // layout above: [4..14] census [15] next unit [16..21] phase cycles [22..28] timeline census; statistics striped from CRT_STATS_BASE; per-wave timeline from CRT_TIMELINE_BASE
 };
 
 #endif

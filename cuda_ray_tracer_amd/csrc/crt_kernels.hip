@@ -491,7 +491,7 @@ __device__ __forceinline__ void unit_next(const crt_render_args& a, unsigned lon
             const unsigned long long t = wall_clock64();
             atomicAdd(&a.counters[22], t); atomicMax(&a.counters[23], t);
             const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-            if (wid < 8192u) a.counters[32 + 3 * wid + 1] = t;
+            if (wid < 8192u) a.counters[CRT_TIMELINE_BASE + 3 * wid + 1] = t;
         }
         ust_st(ust, U_EPOCH, uniform(ust_ld(ust, U_EPOCH)) + 1u);
     } else {
@@ -562,7 +562,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         const unsigned long long t = wall_clock64();
         atomicMax(&a.counters[24], ~t); atomicAdd(&a.counters[27], t); atomicAdd(&a.counters[28], 1ull);
         const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // per-wave records: start, queue empty, exit
-        if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid] = t;
+        if (PERSIST && wid < 8192u) a.counters[CRT_TIMELINE_BASE + 3 * wid] = t;
     }
 #define CRT_LAP(i) do { if (timing) { const long long t_ = (long long)__builtin_readcyclecounter(); tc[i] += (unsigned long long)(t_ - t_mark); t_mark = t_; } } while (0)
 
@@ -985,7 +985,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         const unsigned long long t = wall_clock64();
         atomicAdd(&a.counters[25], t); atomicMax(&a.counters[26], t);
         const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (PERSIST && wid < 8192u) a.counters[32 + 3 * wid + 2] = t;
+        if (PERSIST && wid < 8192u) a.counters[CRT_TIMELINE_BASE + 3 * wid + 2] = t;
     }
 #undef CRT_LAP
 }
@@ -1079,21 +1079,26 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
                 atomicAdd(&a.sums[3 * ((size_t)py * a.cam.width + px) + c], q);
         }
     } else {
-        // simple loop: a wave owns one tile, a lane one pixel and all its samples (brute-force list
-        // world, and the A/B reference of the scheduler)
+        // simple loop: a wave owns one tile and one chunk of its samples, a lane one pixel (brute-force list world, and
+        // the A/B reference of the scheduler).  Small frames get several chunks per tile so that the launch still fills
+        // the chip (C1: 1 407 tiles x 10 samples -> 14 070 waves instead of 1 407 serial ones); the sums are integers,
+        // so the split does not show in the frame.
         if (IN_LDS) __syncthreads();
-        const int share_tile = blockIdx.x * NW + wave;
+        const int unit = blockIdx.x * NW + wave;
+        const int share_tile = unit / a.simple_chunks, chunk = unit - share_tile * a.simple_chunks;
+        const int s_first = (int)((long long)chunk * a.ns / a.simple_chunks);
+        const int s_end = (int)((long long)(chunk + 1) * a.ns / a.simple_chunks);
         const int tile = share_tile * a.tile_stride + a.tile_offset;
         const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
         const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-        const bool valid = (share_tile < a.n_tiles) && (px < a.cam.width) && (py < a.cam.height);
+        const bool valid = (share_tile < a.n_tiles) && (px < a.cam.width) && (py < a.cam.height) && (s_end > s_first);
         const uint32_t pixel_index = (uint32_t)(py * a.cam.width + px);
         if (valid) {
             unsigned long long sx = 0, sy = 0, sz = 0;
             stream rs; rs.k0 = a.key0; rs.k1 = a.key1;
             path_t p;
-            int s = 0;
-            start_path(p, rs, a, px, py, pixel_index, (uint32_t)a.s0);
+            int s = s_first;
+            start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
             for (;;) {
                 hit_t h;
                 if (WORLD == 1) h = closest_hit_bvh<IN_LDS, COUNT>(pairs, spheres, a.num_leaves, p.r, n_pairs, n_tests);
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
                     sx += to_fixed(rad.x); sy += to_fixed(rad.y); sz += to_fixed(rad.z);
                     ++n_samples;
                     ++s;
-                    if (s >= a.ns) break;
+                    if (s >= s_end) break;
                     start_path(p, rs, a, px, py, pixel_index, (uint32_t)(a.s0 + s));
                 }
             }
@@ -1127,10 +1132,12 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     // statistics: one atomic per wave and counter
     {
         const uint32_t r = wave_sum(n_rays), sm = wave_sum(n_samples);
-        if (lane == 0 && r) { atomicAdd(&a.counters[0], (unsigned long long)r); atomicAdd(&a.counters[1], (unsigned long long)sm); }
+        // (the persistent kernel's 6144 waves finish spread over the launch's drain: one stripe, and its code stays as tuned)
+        unsigned long long* stats = a.counters + CRT_STATS_BASE + (SCHED == 2 ? 0 : 4 * (blockIdx.x & (CRT_STAT_STRIPES - 1)));
+        if (lane == 0 && r) { atomicAdd(&stats[0], (unsigned long long)r); atomicAdd(&stats[1], (unsigned long long)sm); }
         if (COUNT) {
             const uint32_t pv = wave_sum(n_pairs), stt = wave_sum(n_tests);
-            if (lane == 0) { atomicAdd(&a.counters[2], (unsigned long long)pv); atomicAdd(&a.counters[3], (unsigned long long)stt); }
+            if (lane == 0) { atomicAdd(&stats[2], (unsigned long long)pv); atomicAdd(&stats[3], (unsigned long long)stt); }
         }
     }
 }

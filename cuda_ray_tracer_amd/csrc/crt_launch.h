@@ -18,7 +18,7 @@ hipError_t crt_launch_trace_samples_fast(const crt_render_args& a, int world, in
 struct crt_frame_list { const unsigned long long* p[CRT_GROUP_MAX]; int n; };
 hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& src, size_t count, hipStream_t stream);
 // crt_static.hip: the per-GPU static scratch of crt_render_static (counters first, then the frame's int64 sums)
-#define CRT_STATIC_COUNTER_WORDS (32 + 3 * 8192)   // = the size of a context's counter buffer; 196 864 B, a multiple of 256
+#define CRT_STATIC_COUNTER_WORDS CRT_COUNTER_WORDS   // = the size of a context's counter buffer; 198 912 B, a multiple of 256
 #define CRT_STATIC_MAX_PIXELS_ (1u << 21)          // == CRT_STATIC_MAX_PIXELS of include/crt_hip.h
 hipError_t crt_static_scratch(int device, unsigned long long** out);
 hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream);

@@ -15,6 +15,7 @@
 
 #include "crt_launch.h"
 
+static_assert((CRT_STATIC_COUNTER_WORDS * sizeof(unsigned long long)) % 256 == 0, "the sums must start 256-byte aligned");
 static __device__ __align__(256) unsigned long long scratch[CRT_STATIC_COUNTER_WORDS + 3ull * CRT_STATIC_MAX_PIXELS_];
 
 namespace {
