@@ -44,10 +44,15 @@ def parse_args(argv=None):
     ap.add_argument("--scene-seed", type=int, default=18)
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="target CPU time of each cpu_baseline sample (0 = skip)")
-    ap.add_argument("--config", choices=["c1", "c2", "c4"], default="c2",
+    ap.add_argument("--config", choices=["c1", "c2", "c4", "c5"], default="c2",
                     help="c2 = BASELINE configs[1] (the metric's config, default); c1 = configs[0], the 5-sphere scene through "
                          "the brute-force list world (400x225, 10 spp, depth 10); c4 = configs[3], the synthetic 1M-sphere "
-                         "HBM stress (1920x1080, 64 spp) -- c1/c4 are DESIGN.md measurements, not the driver's line")
+                         "HBM stress (1920x1080, 64 spp); c5 = configs[4], the random-spheres scene at 3840x2160, 1024 spp, "
+                         "rendered progressively in --passes launches per image -- c1/c4/c5 are DESIGN.md measurements, not "
+                         "the driver's line")
+    ap.add_argument("--passes", type=int, default=0,
+                    help="progressive accumulation: every rank cuts its share of an image into this many launches into the "
+                         "same sums buffer (default 1; 8 for --config c5); one reduce + resolve per image")
     ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
                     help="N > 1: rank g traces samples [g spp/N, (g+1) spp/N) of every pixel (default, north_star), or "
                          "all samples of the 8x8 tiles t = g mod N")
@@ -261,6 +266,10 @@ def main():
             args.width, args.spp = 1920, 64
     if args.config == "c1" and args.width == 1200 and args.spp == 500 and args.depth == 50:
         args.width, args.spp, args.depth = 400, 10, 10
+    if args.config == "c5" and args.width == 1200 and args.spp == 500:
+        args.width, args.spp = 3840, 1024
+    passes = args.passes if args.passes > 0 else (8 if args.config == "c5" else 1)
+    args.passes = passes
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -280,9 +289,21 @@ def main():
     share = share_of_rank(args.spp, world_size, rank, args.split)
     has_work = share["nsamples"] > 0
 
+    rays_of_passes = []
+
+    def trace_in_passes(first, count, tile_stride, tile_offset, count_rays=False):
+        # progressive accumulation (crt_render_accumulate ADDS): the share's samples in `passes` launches, same buffer
+        for q in range(passes):
+            lo, hi = first + q * count // passes, first + (q + 1) * count // passes
+            if hi > lo:
+                g.trace(lo, hi - lo, tile_stride, tile_offset)
+                if count_rays:
+                    st_q = g.r.stats()
+                    rays_of_passes.append((st_q.rays, st_q.samples))
+
     def step():  # zero, trace this rank's share, RCCL reduce(SUM) to rank 0, resolve to fp32 there.  EVERY rank calls it.
-        render_split(g.trace, g.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split,
-                     host_staged=args.share_gpu)
+        render_split(trace_in_passes if passes > 1 else g.trace, g.sums, args.spp, world_size, rank, always_reduce=use_dist,
+                     split=args.split, host_staged=args.share_gpu)
         if rank == 0:
             g.resolve(args.spp)
 
@@ -312,7 +333,12 @@ def main():
         # per-launch kernel time of the TIMED steps: HIP events the library records on the launch
         # stream around every launch (it keeps the last 64)
         if has_work and args.steps > 0:
-            kernel_s = g.r.kernel_times(min(args.steps, 64))
+            kernel_s = g.r.kernel_times(min(args.steps * passes, 64))
+        if has_work and passes > 1:  # rays of one image = the sum over its passes: one more, untimed, image with a read-back per pass
+            g.sums.zero_()
+            trace_in_passes(share["first"], share["nsamples"], share["tile_stride"], share["tile_offset"], count_rays=True)
+            rays_rank = float(sum(v[0] for v in rays_of_passes))
+            samples_rank = float(sum(v[1] for v in rays_of_passes))
 
     t = torch.tensor([elapsed, rays_rank, samples_rank], dtype=torch.float64, device="cpu" if args.share_gpu else g.dev)
     if use_dist:
@@ -379,7 +405,8 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
     S = cst.sphere_tests / cst.rays
     flops_per_ray = 50.0 * I + 45.0 * S + 60.0
     bytes_per_ray = 64.0 * I + 32.0 * S
-    kavg = float(np.mean(kernel_s))
+    passes = args.passes
+    kavg = float(np.mean(kernel_s)) * passes  # kernel time of one image's launches on this rank
     achieved_tflops = flops_per_ray * cst.rays / kavg / 1e12
     roofline = {
         "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -421,6 +448,9 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
     if args.config == "c1":
         out["config"]["workload"] = (f"RTOW small scene (helper.h:7-35, 5 spheres), {W}x{H}, {args.spp} spp, depth {args.depth}, "
                                      "brute-force hittable_list world")
+    if passes > 1:
+        out["config"]["passes"] = passes
+        out["config"]["workload"] += f", progressive in {passes} launches per image"
     if args.config == "c4":
         out["config"]["workload"] = (f"synthetic {g.scene.n}-sphere scene (helper.h:37-102 generator on a 1000x1000 grid, "
                                      f"ground r=1e5), {W}x{H}, {args.spp} spp, depth {args.depth}, flat BVH in HBM")
