@@ -66,3 +66,34 @@ def test_static_entry_point_matches_crt_render(crt):
     torch.cuda.synchronize()
     assert _bits_equal(out.cpu().numpy(), want)
     r2.close()
+
+
+def test_static_entry_point_under_graph_capture(crt):
+    """The caller the entry point exists for: one crt_render_static call captured into a HIP graph (stream capture
+    forbids allocation), replayed three times; every replay must produce crt_render's frame.  (crt_render could not be
+    captured: it sizes its buffers with hipMalloc and copies to the host synchronously.)"""
+    import torch
+    r = crt.Renderer(0, 3)
+    r.upload_scene(crt.scene_random(18, 11))
+    r.build_bvh(17)
+    cam = crt.camera(640, 6)
+    r.set_camera(cam)
+    want, _ = r.render(crt.CRT_WORLD_BVH, 6, 0, 50)
+    out = torch.zeros((cam.image_height, 640, 3), dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # warm-up outside the capture: code objects, the scratch array's address
+        r.render_static(crt.CRT_WORLD_BVH, 6, 0, 50, out.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        r.render_static(crt.CRT_WORLD_BVH, 6, 0, 50, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0  # capture records, it does not run
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert _bits_equal(out.cpu().numpy(), want)
+    del g
+    r.close()
