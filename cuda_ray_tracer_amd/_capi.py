@@ -10,17 +10,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(_HERE, "libcrt_hip.so")  # CRT_LIB_PATH: A/B of two builds (tools)
 
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "crt_hip.h")
+
+
+def header_exports(path=HEADER_PATH):
+    """Every function include/crt_hip.h declares, read from its prototypes (so the export check of
+    __graft_entry__.build() and tests/test_host_parity.py cannot drift from the header)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", open(path).read(), flags=re.S)   # comments out
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)                  # preprocessor lines out
+    text = re.sub(r"\{[^{}]*\}", " ", text)                           # struct / enum bodies out (none nest)
+    names = re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
 # every symbol include/crt_hip.h declares
-EXPORTS = [
-    "crt_camera_initialize", "crt_scene_small", "crt_scene_random", "crt_write_ppm", "crt_bvh_num_nodes",
-    "crt_bvh_build_host", "crt_create", "crt_destroy", "crt_last_error", "crt_set_seed", "crt_upload_scene",
-    "crt_build_bvh", "crt_get_bvh_nodes", "crt_set_camera", "crt_render", "crt_render_accumulate",
-    "crt_resolve", "crt_get_stats", "crt_get_kernel_times", "crt_set_count_stats", "crt_trace_samples",
-    "crt_upload_bvh_nodes", "crt_render_accumulate_tiles", "crt_set_arith", "crt_last_kernel_name", "crt_build_id",
-    "crt_group_create", "crt_group_destroy", "crt_group_size", "crt_group_member", "crt_group_last_error",
-    "crt_group_upload_scene", "crt_group_build_bvh", "crt_group_upload_bvh_nodes", "crt_group_set_camera",
-    "crt_group_render", "crt_render_static",
-]
+EXPORTS = header_exports()
 
 CRT_LAMBERTIAN, CRT_METAL, CRT_DIELECTRIC, CRT_MATERIAL_BASE = 0, 1, 2, 3
 CRT_WORLD_LIST, CRT_WORLD_BVH = 0, 1

@@ -44,6 +44,7 @@ struct crt_context {
     int dbg_cap = 0;
     static constexpr int EV_RING = 64;  // event pairs of the most recent launches
     hipEvent_t ev_ring[2 * EV_RING] = {};
+    bool ev_timed[EV_RING] = {};  // false: the launch was captured into a graph, its events were not recorded
     long launches = 0;
     bool launched = false;
     double wall_seconds = 0;
@@ -348,13 +349,20 @@ int crt_set_camera(crt_context* ctx, const crt_camera* cam) {
     return CRT_OK;
 }
 
-static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int max_depth, int tile_stride, int tile_offset,
-                     unsigned long long* d_sums, unsigned long long* counters, crt_render_args& a) {
+// state and argument checks of every render entry point; nothing is enqueued before they pass
+static int validate_render(crt_context* ctx, int world, int s0, int ns, int max_depth) {
     if (!ctx->have_cam) return fail(ctx, CRT_ERR_STATE, "render: no camera set");
     if (ctx->n < 1) return fail(ctx, CRT_ERR_STATE, "render: no scene uploaded");
     if (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: unknown world kind");
     if (world == CRT_WORLD_BVH && !ctx->d_pairs) return fail(ctx, CRT_ERR_STATE, "render: CRT_WORLD_BVH needs crt_build_bvh first");
     if (ns < 1 || s0 < 0 || max_depth < 1) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "render: nsamples, sample_offset or max_depth out of range");
+    if (ns > (1 << 20)) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^20 samples in one call (split the range)");
+    return CRT_OK;
+}
+
+static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int max_depth, int tile_stride, int tile_offset,
+                     unsigned long long* d_sums, unsigned long long* counters, crt_render_args& a) {
+    if (int rc = validate_render(ctx, world, s0, ns, max_depth)) return rc;
     const crt_camera& c = ctx->cam;
     memcpy(a.cam.center, c.center, 12); memcpy(a.cam.p00, c.pixel00_loc, 12);
     memcpy(a.cam.du, c.pixel_delta_u, 12); memcpy(a.cam.dv, c.pixel_delta_v, 12);
@@ -365,7 +373,6 @@ static int fill_args(crt_context* ctx, int world, int block, int s0, int ns, int
     a.num_leaves = ctx->num_leaves; a.n = ctx->n; a.m = ctx->m;
     a.key0 = uint32_t(ctx->seed); a.key1 = uint32_t(ctx->seed >> 32);
     a.s0 = s0; a.ns = ns;
-    if (ns > (1 << 20)) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^20 samples in one call (split the range)");
     // tiles per workgroup: enough (pixel, sample) items that every thread gets >= 16 of them
     int t = ctx->tiles_per_wg;
     if (t == 0) { t = 1; while (t < 16 && int64_t(64) * t * ns < int64_t(16) * block) t <<= 1; }
@@ -467,10 +474,16 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
     CRT_HIP_TRY(ctx, hipMemsetAsync(counters, 0, CRT_TIMELINE_BASE * sizeof(unsigned long long), stream));  // census + striped statistics
     const int slot = int(ctx->launches % crt_context::EV_RING);
     const bool fast = ctx->arith == CRT_ARITH_FAST;
-    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
+    // Under stream capture (crt_render_static exists for it) an event record would become a graph node and the
+    // event would never be recorded on a real stream: the slot is marked untimed instead (kernel_seconds = 0).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool timed = cap == hipStreamCaptureStatusNone;
+    if (timed) CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot], stream));
     if (tiles > 0)  // (a share beyond the last tile is empty: nothing to launch, the statistics read zero)
         CRT_HIP_TRY(ctx, (fast ? crt_launch_render_fast : crt_launch_render)(a, world, in_lds, ctx->count_stats, block, grid, lds, stream));
-    CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
+    if (timed) CRT_HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[2 * slot + 1], stream));
+    ctx->ev_timed[slot] = timed;
     ctx->launches += 1;
     ctx->launched = true;
     ctx->last_counters = counters;
@@ -505,6 +518,8 @@ int crt_render_static(crt_context* ctx, int32_t world, int32_t spp, int32_t samp
         return fail(ctx, CRT_ERR_TOO_LARGE, "crt_render_static: frame of " + std::to_string(pixels) + " pixels exceeds the static scratch (" +
                                                 std::to_string(CRT_STATIC_MAX_PIXELS) + " pixels); use crt_render / crt_render_accumulate");
     static_assert(CRT_STATIC_MAX_PIXELS == CRT_STATIC_MAX_PIXELS_, "header and scratch size disagree");
+    // every check first: a rejected call enqueues nothing (under capture: adds no node to the graph)
+    if (int rc = validate_render(ctx, world, sample_offset, spp, max_depth)) return rc;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // The address of THIS GPU's copy of the array: resolved on the first call on a device (crt_static.hip caches it
     // per device).  Resolving it at crt_create would make every context pay for loading the array (17 ms measured for
@@ -536,9 +551,13 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     if (!ctx->launched) return fail(ctx, CRT_ERR_STATE, "crt_get_stats: nothing launched yet");
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int slot = int((ctx->launches - 1) % crt_context::EV_RING);
-    CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
     float ms = 0;
-    CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+    if (ctx->ev_timed[slot]) {
+        CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
+        CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+    } else {
+        CRT_HIP_TRY(ctx, hipDeviceSynchronize());  // a captured launch: no events; the counters are read after the device is idle
+    }
     unsigned long long stripes[4 * CRT_STAT_STRIPES], c[4] = {0, 0, 0, 0};
     CRT_HIP_TRY(ctx, hipMemcpy(stripes, ctx->last_counters + CRT_STATS_BASE, sizeof stripes, hipMemcpyDeviceToHost));
     for (int i = 0; i < CRT_STAT_STRIPES; ++i)
@@ -556,9 +575,11 @@ int crt_get_kernel_times(crt_context* ctx, int32_t count, double* seconds_out) {
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int i = 0; i < count; ++i) {  // oldest of the `count` most recent launches first
         const int slot = int((ctx->launches - count + i) % crt_context::EV_RING);
-        CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
         float ms = 0;
-        CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+        if (ctx->ev_timed[slot]) {  // (a launch captured into a graph is untimed: 0)
+            CRT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
+            CRT_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+        }
         seconds_out[i] = ms * 1e-3;
     }
     return CRT_OK;
@@ -579,7 +600,7 @@ int crt_debug_timeline(crt_context* ctx, uint64_t* out, int32_t waves) {
     if (!ctx || !out || waves < 1 || waves > 8192) return CRT_ERR_INVALID_ARGUMENT;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     CRT_HIP_TRY(ctx, hipDeviceSynchronize());
-    CRT_HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters + CRT_TIMELINE_BASE, size_t(waves) * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(out, (ctx->last_counters ? ctx->last_counters : ctx->d_counters) + CRT_TIMELINE_BASE, size_t(waves) * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
@@ -734,16 +755,21 @@ int crt_group_create(const int32_t* devices, int32_t n, uint64_t seed, crt_group
         }
         g->streams.push_back(st); g->done.push_back(ev);
     }
-    // peer access from members[0]'s device to the others makes the frame copies direct xGMI transfers; the copies
-    // work without it (staged by the runtime), so a refusal is not an error
-    (void)hipSetDevice(devices[0]);
+    // peer access between members[0]'s device and the others, BOTH ways: crt_group_render issues member i's frame copy
+    // on member i's stream (device i writes into the staging buffer on devices[0]), and devices[0] may read the others;
+    // with it the copies are direct xGMI transfers.  They work without it (staged by the runtime), so a refusal is
+    // not an error.
     for (int i = 1; i < n; ++i) {
-        int can = 0;
-        if (devices[i] != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
-            if (e != hipSuccess) (void)hipGetLastError();  // already enabled, or not possible: clear the sticky error
+        if (devices[i] == devices[0]) continue;
+        const int pair[2][2] = {{devices[0], devices[i]}, {devices[i], devices[0]}};  // {accessing device, peer}
+        for (const auto& pr : pair) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, pr[0], pr[1]) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            if (hipSetDevice(pr[0]) != hipSuccess || hipDeviceEnablePeerAccess(pr[1], 0) != hipSuccess)
+                (void)hipGetLastError();  // already enabled, or not possible: clear the sticky error
         }
     }
+    (void)hipSetDevice(devices[0]);
     g->sums.assign(size_t(n), nullptr);
     g->staging.assign(size_t(n > 1 ? n - 1 : 0), nullptr);
     *out = g;

@@ -37,6 +37,14 @@
 // build also turns the SLP vectorizer off for the same reason, see the Makefile)
 
 namespace {
+// One inline namespace per arithmetic mode: the two translation units then emit DIFFERENT kernel symbols
+// ((anonymous namespace)::arith_exact::render_kernel<...> / ...::arith_fast::...), so rocprofv3 --stats keeps the
+// modes apart (with identical symbols it blended their dispatches into one row).
+#if CRT_FAST
+inline namespace arith_fast {
+#else
+inline namespace arith_exact {
+#endif
 
 struct v3 { float x, y, z; };
 
@@ -1224,6 +1232,7 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
     return hipErrorInvalidValue;
 }
 
+}  // inline namespace arith_exact / arith_fast
 }  // namespace
 
 #if !CRT_FAST

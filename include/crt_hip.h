@@ -202,7 +202,10 @@ int crt_render_accumulate_tiles(crt_context* ctx, int32_t world, int32_t sample_
  * call makes no hipMalloc / hipFree.  As with any kernel, the FIRST call on a GPU makes the runtime load code objects
  * (the render kernels' and the array's): make one warm-up call before entering a region that must not allocate.  Limit: frames of at most CRT_STATIC_MAX_PIXELS pixels; larger ones are rejected
  * with CRT_ERR_TOO_LARGE.  All calls on one GPU share that GPU's array -- calls that overlap on one GPU (two streams,
- * two contexts, two threads) race; order them. */
+ * two contexts, two threads) race; order them.  Every state / argument check runs before any stream work: a
+ * rejected call enqueues nothing (under capture it adds no node).  A call made while `stream` is capturing records no
+ * timing events (they would become graph nodes): crt_get_stats then returns the counters with kernel_seconds = 0 and
+ * crt_get_kernel_times reports 0 for that launch; graph replays are never timed by the library. */
 #define CRT_STATIC_MAX_PIXELS (1 << 21)
 int crt_render_static(crt_context* ctx, int32_t world, int32_t spp, int32_t sample_offset, int32_t max_depth,
                       float* d_fb, void* stream);

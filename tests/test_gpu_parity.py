@@ -308,7 +308,7 @@ def test_degenerate_ray_directions(crt, orc, rnd, small, vfov, env):
         r.close()
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("CRT_FUZZ_CASES", "12"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("CRT_FUZZ_CASES", "48"))))
 def test_fuzz_scene_camera_depth(crt, orc, case):
     """Seeded random configurations: scene size (LDS image or HBM path), camera inside / outside the
     scene, field of view, defocus, ragged frame sizes, sample offset, depth 1..50 -- frame, ray count

@@ -90,10 +90,34 @@ def test_static_entry_point_under_graph_capture(crt):
         r.render_static(crt.CRT_WORLD_BVH, 6, 0, 50, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert float(out.abs().sum()) == 0.0  # capture records, it does not run
+    _, st_want = r.render(crt.CRT_WORLD_BVH, 6, 0, 50)
     for _ in range(3):
         out.zero_()
         g.replay()
         torch.cuda.synchronize()
         assert _bits_equal(out.cpu().numpy(), want)
-    del g
+    # the captured call recorded no timing events (they would have become graph nodes): statistics still work --
+    # the counters of the last replay, kernel_seconds = 0 -- and so does the ring of kernel times
+    r.render_static(crt.CRT_WORLD_BVH, 6, 0, 50, out.data_ptr(), s.cuda_stream)   # timed, un-captured
+    s.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        r.render_static(crt.CRT_WORLD_BVH, 6, 0, 50, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    g2.replay()
+    torch.cuda.synchronize()
+    st = r.stats()
+    assert st.kernel_seconds == 0.0 and st.rays == st_want.rays and st.samples == st_want.samples
+    kt = r.kernel_times(2)
+    assert kt[0] > 0.0 and kt[1] == 0.0
+    # a rejected call enqueues nothing: under capture it must add no node (here: unknown world kind)
+    g3 = torch.cuda.CUDAGraph()
+    out.zero_()
+    with torch.cuda.graph(g3, stream=s):
+        with pytest.raises(crt.CrtError):
+            r.render_static(7, 6, 0, 50, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        out.add_(1.0)  # so that the graph is not empty
+    g3.replay()
+    torch.cuda.synchronize()
+    assert float(out.min()) == 1.0 and float(out.max()) == 1.0
+    del g, g2, g3
     r.close()
