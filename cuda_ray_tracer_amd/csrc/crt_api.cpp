@@ -59,6 +59,7 @@ struct crt_context {
     size_t lds_limit = 126 * 1024;  // scene image that still leaves room for one 16-wave workgroup per CU (55 KB: two 12-wave ones)
     int sched = 1, leaf_num = 2, shade_num = 12, run_shift = 1;
     int tail_pass = 1;
+    int walkers = 4, refill_min = 16, owner_sleep = 4, walker_backoff = 2, walker_prio = 1, walker_min_busy = 0, walker_patience = 8;  // SCHED=3 (CRT_SCHED=3): walker waves per workgroup, refill threshold, poll interval
     int top_pairs_max = 1024;  // CRT_TOP_PAIRS
     int persist = 1, unit_samples = 0;  // persistent waves; samples per coarse unit (0: chosen per launch)
     int fine_samples = 0, fine_pct = 30;  // samples per fine unit (0: a quarter of the coarse ones), share of the samples cut into fine units
@@ -139,7 +140,14 @@ int crt_create(int32_t device, uint64_t seed, crt_context** out) {
     ctx->seed = seed;
     if (const char* b = getenv("CRT_BLOCK")) { int v = atoi(b); if (v == 256 || v == 512 || v == 768 || v == 1024) ctx->block = v; }
     if (const char* b = getenv("CRT_TILES")) { int v = atoi(b); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->tiles_per_wg = v; }
-    if (const char* b = getenv("CRT_SCHED")) ctx->sched = atoi(b) != 0;
+    if (const char* b = getenv("CRT_SCHED")) { const int v = atoi(b); ctx->sched = v == 3 ? 3 : (v != 0); }
+    if (const char* b = getenv("CRT_WALKERS")) { int v = atoi(b); if (v >= 1 && v <= 8) ctx->walkers = v; }
+    if (const char* b = getenv("CRT_REFILL_MIN")) { int v = atoi(b); if (v >= 1 && v <= 64) ctx->refill_min = v; }
+    if (const char* b = getenv("CRT_OWNER_SLEEP")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->owner_sleep = v; }
+    if (const char* b = getenv("CRT_WALKER_BACKOFF")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->walker_backoff = v; }
+    if (const char* b = getenv("CRT_WALKER_PRIO")) ctx->walker_prio = atoi(b) != 0;
+    if (const char* b = getenv("CRT_WALKER_MIN_BUSY")) { int v = atoi(b); if (v >= 0 && v <= 64) ctx->walker_min_busy = v; }
+    if (const char* b = getenv("CRT_WALKER_PATIENCE")) { int v = atoi(b); if (v >= 0 && v <= 4096) ctx->walker_patience = v; }
     if (const char* b = getenv("CRT_RUN_SHIFT")) { int v = atoi(b); if (v >= 0 && v <= 6) ctx->run_shift = v; }
     if (const char* b = getenv("CRT_LDS_LIMIT")) ctx->lds_limit = size_t(atol(b));
     if (const char* b = getenv("CRT_LEAF_NUM")) { int v = atoi(b); if (v >= 0 && v <= 16) ctx->leaf_num = v; }
@@ -417,25 +425,35 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
         else
             block = !in_lds || scene_bytes <= 50 * 1024 ? 512 : (scene_bytes <= 78 * 1024 ? 768 : 1024);
     }
+    // SCHED=3 (walker + owner waves): LDS-resident trees under persistent waves only, 12- or 16-wave workgroups
+    const bool split_waves = scheduled && ctx->sched == 3 && ctx->persist && in_lds;
+    if (split_waves && block != 768 && block != 1024) block = scene_bytes <= 52 * 1024 ? 768 : 1024;
     crt_render_args a;
     memset(&a, 0, sizeof a);
     if (int rc = fill_args(ctx, world, block, sample_offset, nsamples, max_depth, tile_stride, tile_offset,
                            (unsigned long long*)d_sums, counters, a)) return rc;
+    if (!split_waves && a.sched == 3) a.sched = 1;
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
     const int nw = block / 64;
+    const int n_walk = split_waves ? (ctx->walkers < nw - 1 ? ctx->walkers : nw - 1) : 0;
+    const int n_own = nw - n_walk;  // waves that own paths (all of them without walkers)
     const int64_t tiles = a.n_tiles;  // of this launch's share
     size_t lds = in_lds ? scene_bytes : 48 * size_t(top_pairs);
     int grid;
     if (scheduled && ctx->persist) {
         // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
         // wave pulling (tile, sample chunk) units; coarse units sized for about 16 per wave, 8..32 samples each
-        lds += size_t(nw) * 260 * 8;  // per wave: one tile of accumulators, its unit state, 32 block requests
+        lds += size_t(n_own) * 260 * 8;  // per path-owning wave: one tile of accumulators, its unit state, 32 block requests
+        if (split_waves) lds += size_t(n_own) * 16 * (2 * 32 + 1 + 16);  // + its request ring, control words and mailboxes (CRT_XCHG_FLOAT4_PER_OWNER)
+        a.n_walkers = n_walk; a.refill_min = ctx->refill_min; a.owner_sleep = ctx->owner_sleep;
+        a.walker_backoff = ctx->walker_backoff; a.walker_prio = ctx->walker_prio;
+        a.walker_min_busy = ctx->walker_min_busy; a.walker_patience = ctx->walker_patience;
         int per_cu = int((160 * 1024) / (lds > 0 ? lds : 1));
         const int by_waves = 24 / nw;  // 6 waves per SIMD: the kernel stays within 80 VGPRs
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
-        const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * nw;
+        const int64_t resident_waves = int64_t(ctx->num_cus) * per_cu * n_own;
         int us = ctx->unit_samples;
         if (us == 0) { us = int(int64_t(ns_) * tiles / (16 * resident_waves)); us = us < 8 ? 8 : (us > 32 ? 32 : us); }
         a.persist = 1;
@@ -455,7 +473,7 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
         const int64_t units = tiles * (int64_t(a.unit_chunks) + a.fine_chunks);
         if (units > (1ll << 31) - 1) return fail(ctx, CRT_ERR_TOO_LARGE, "render: more than 2^31-1 work units (split the sample range)");
         a.n_units = int(units);
-        const int64_t wgs = (units + nw - 1) / nw;
+        const int64_t wgs = (units + n_own - 1) / n_own;
         grid = int(wgs < int64_t(ctx->num_cus) * per_cu ? wgs : int64_t(ctx->num_cus) * per_cu);
     } else {
         // simple loop: one wave per (tile, sample chunk); enough chunks that a small frame still fills the chip
@@ -487,7 +505,7 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
     ctx->launches += 1;
     ctx->launched = true;
     ctx->last_counters = counters;
-    const int sched_id = world == CRT_WORLD_BVH ? (ctx->sched ? (ctx->persist ? 2 : 1) : 0) : 0;
+    const int sched_id = world == CRT_WORLD_BVH ? (ctx->sched ? (ctx->persist ? (split_waves ? 3 : 2) : 1) : 0) : 0;
     snprintf(ctx->last_kernel, sizeof ctx->last_kernel, "render_kernel<WORLD=%s, IN_LDS=%d, COUNT=%d, BLOCK=%d, SCHED=%d>%s",
              world == CRT_WORLD_BVH ? "BVH" : "LIST", int(in_lds), int(ctx->count_stats), block, sched_id, fast ? " [arith=fast]" : "");
     return CRT_OK;
@@ -558,8 +576,10 @@ int crt_get_stats(crt_context* ctx, crt_render_stats* stats) {
     } else {
         CRT_HIP_TRY(ctx, hipDeviceSynchronize());  // a captured launch: no events; the counters are read after the device is idle
     }
-    unsigned long long stripes[4 * CRT_STAT_STRIPES], c[4] = {0, 0, 0, 0};
+    unsigned long long stripes[4 * CRT_STAT_STRIPES], c[4] = {0, 0, 0, 0}, watchdog = 0;
     CRT_HIP_TRY(ctx, hipMemcpy(stripes, ctx->last_counters + CRT_STATS_BASE, sizeof stripes, hipMemcpyDeviceToHost));
+    CRT_HIP_TRY(ctx, hipMemcpy(&watchdog, ctx->last_counters + 29, sizeof watchdog, hipMemcpyDeviceToHost));
+    if (watchdog != 0) return fail(ctx, CRT_ERR_HIP, "render: the walker/owner exchange watchdog fired (" + std::to_string(watchdog) + " waves gave up waiting): the frame is incomplete");
     for (int i = 0; i < CRT_STAT_STRIPES; ++i)
         for (int j = 0; j < 4; ++j) c[j] += stripes[4 * i + j];
     stats->kernel_seconds = ms * 1e-3;

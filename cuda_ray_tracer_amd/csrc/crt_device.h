@@ -35,7 +35,8 @@
 #endif
 
 // counter buffer of a launch (unsigned long long words):
-//   [0, 32)                            census, work-queue counter [15], phase cycles, timeline sums (crt_render_args::counters)
+//   [0, 32)                            census, work-queue counter [15], phase cycles, timeline sums (crt_render_args::counters);
+//                                      [29] exchange watchdog of SCHED=3 (must stay 0)
 //   [CRT_STATS_BASE, + 4 * STRIPES)    rays, samples, pair visits, sphere tests -- striped over 64 slots by workgroup: every
 //                                      wave adds its totals once, and thousands of atomics on ONE address serialise in L2
 //                                      (10 ns each: 0.28 ms for the 28 000 of a small frame's launch)
@@ -68,7 +69,7 @@ struct crt_render_args {
     int tile_stride, tile_offset, n_tiles;
     int simple_chunks;       // simple loop (list world, SCHED=0): a tile's ns samples are cut into this many chunks, one wave each
     int max_depth;
-    int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop
+    int sched;               // 1: wave-scheduled BVH tracer, 0: simple per-lane loop, 3: wave-scheduled with walker waves
     int census;              // COUNT variant only: also count scheduler iterations / served lanes per phase
     int run_shift;           // leave the box-walking loop once n_run >> run_shift lanes have left it
     int leaf_num, shade_num; // run the sphere / shade phase once >= num/16 of the live lanes wait for it
@@ -86,6 +87,14 @@ struct crt_render_args {
     int n_units;             // n_coarse + n_tiles * fine_chunks
     int top_pairs;           // scheduled, scene in HBM: pair records [0, top_pairs) are also staged in LDS (power of two <= L, or 0)
     int tail_pass;           // persistent: whole-wave speculative draws for the last rejection-sampling lanes
+    // SCHED=3 (sched == 3): the first n_walkers waves of a workgroup only walk boxes for the others (crt_kernels.hip walker_loop)
+    int n_walkers;           // walker waves per workgroup
+    int refill_min;          // a walker refills its idle lanes from the request rings once this many are idle
+    int owner_sleep;         // an owner wave (or a wholly idle walker) with nothing to do sleeps this many times 64 clocks between polls
+    int walker_backoff;      // a walker that found its rings empty walks this many steps before it looks again
+    int walker_prio;         // 1: walker waves run at raised priority (s_setprio 2)
+    int walker_min_busy;     // a walker with fewer rays on board polls for more (at most walker_patience times in a row) before it steps; 0: off
+    int walker_patience;
     unsigned long long* sums;  // [3 * W * H] fixed-point (2^-40) RGB sums, row-major
     unsigned long long* counters;  // layout above: [4..14] census [15] next unit [16..21] phase cycles [22..28] timeline census; statistics striped from CRT_STATS_BASE; per-wave timeline from CRT_TIMELINE_BASE
 };

@@ -537,10 +537,217 @@ struct walk_scene {
     uint32_t L;               // num_leaves
 };
 
-template <bool IN_LDS, bool COUNT, bool PERSIST>
+// ---------------------------------------------------------------------------------------
+// SCHED=3: the extend stage split out into WALKER waves (north_star's generate / extend / shade alternative, with the
+// queues in LDS instead of HBM).  The first `n_walkers` waves of a workgroup only walk boxes: each of their lanes holds
+// one compact walk request (origin, 1/d, interval end, node index, pending mask) and is refilled from a request ring
+// the step after it reaches a leaf or finishes, so the walking step runs with (nearly) all 64 lanes.  The other waves
+// are OWNERS: the scheduled tracer below without its walking loop -- they post a request whenever one of their rays
+// has boxes to walk and run the sphere and shade phases on what comes back.  Every ray's own operation sequence is
+// unchanged (the walker executes exactly the steps the owner lane would have), so the frame is bit-identical.
+//
+// Exchange, all in LDS, per OWNER wave (single producer, single consumer: walker j serves the owners o = j mod n_walkers):
+//   ring   CRT_RING_CAP entries of two float4 (SoA): { o.xyz, best_t }, { inv.xyz, k | pending << 12 | owner lane << 26 }
+//   ctl    { tail (owner writes), head (walker writes), done (owner writes once), - }
+//   mbox   64 words, one per owner lane: the walker's answer  VALID | k | pending << 12  (k == 0: finished; k >= L:
+//          leaf held for the sphere phase, bit 0 of pending = its sibling was hit too)
+// DS operations of one wave execute in issue order, so "entry, then tail" / "entry read, then head" need no more
+// than the compiler keeping that order (workgroup-scope fences).
+#define CRT_RING_CAP 32u
+#define CRT_MBOX_VALID 0x80000000u
+#define CRT_XCHG_FLOAT4_PER_OWNER (2 * CRT_RING_CAP + 1 + 16)  // ring halves, ctl, 64 mailbox words
+
+struct owner_link {
+    uint32_t q0, q1;  // LDS byte offsets of the two ring halves of this owner wave
+    uint32_t ctl;     // LDS byte offset of { tail, head, done, - }
+    uint32_t mbox;    // LDS byte offset of its 64 mailbox words
+};
+
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)p; }  // low half of a flat LDS address
+__device__ __forceinline__ uint32_t xl_ld(uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    return __hip_atomic_load((lds_u32*)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    return off;
+#endif
+}
+__device__ __forceinline__ void xl_st(uint32_t off, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    __hip_atomic_store((lds_u32*)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ f4 xl_ld4(uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const volatile f4 lds_f4;
+    return *(lds_f4*)off;
+#else
+    return f4{0, 0, 0, 0};
+#endif
+}
+__device__ __forceinline__ void xl_st4(uint32_t off, f4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) volatile f4 lds_f4;
+    *(lds_f4*)off = v;
+#endif
+}
+__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// A walker wave (SCHED=3).  xchg: LDS byte offset of the owners' exchange areas (CRT_XCHG_FLOAT4_PER_OWNER float4 each);
+// this walker serves the owners first, first + stride, ... < n_owners.
+template <bool COUNT>
+__device__ __forceinline__ void walker_loop(const crt_render_args& a, const walk_scene& ws, uint32_t xchg, uint32_t first,
+                                            uint32_t stride, uint32_t n_owners, uint32_t& n_pairs) {
+    const float tmin = 0.001f;
+    const float4* pairs = ws.pairs;
+    const uint32_t NL = ws.L;
+    const int lane = threadIdx.x & 63;
+    v3 o = mk(0, 0, 0), inv = mk(1, 1, 1);
+    float best_t = 0.0f;
+    uint32_t k = 0, pending = 0, dst = 0;
+    uint32_t offx = 0, offy = 0, offz = 0;
+    bool exact = false, busy = false;
+    const int refill_min = a.refill_min;
+    unsigned long long c_refills = 0, c_taken = 0, c_idle = 0, c_steps = 0, c_busy = 0;  // census
+    uint32_t rr = 0;           // which of its owners the walker visits first (rotates)
+    uint32_t idle_polls = 0;   // watchdog: consecutive polls that found nothing
+    int backoff = 0, patience = a.walker_patience;
+    if (a.walker_prio) __builtin_amdgcn_s_setprio(2);
+    for (;;) {
+        const unsigned long long m_idle = __ballot(!busy);
+        const int n_idle = __popcll(m_idle);
+        if (backoff > 0 && n_idle < 64) --backoff;  // the rings were empty a moment ago: walk a few steps before looking again
+        else if (n_idle >= refill_min) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+            uint32_t taken = 0;
+            bool all_done = true;
+            uint32_t ow = first + rr * stride;
+            if (ow >= n_owners) { ow = first; rr = 0; }
+            for (uint32_t i = first; i < n_owners; i += stride) {
+                const uint32_t base = xchg + ow * (16u * CRT_XCHG_FLOAT4_PER_OWNER);
+                const uint32_t ctl = base + 32u * CRT_RING_CAP;
+                const f4 cw = xl_ld4(ctl);  // { tail, head, done, - } in one read
+                const uint32_t tail = uniform(__float_as_uint(cw.x)), head = uniform(__float_as_uint(cw.y));
+                all_done = all_done && (uniform(__float_as_uint(cw.z)) != 0u);
+                const uint32_t avail = tail - head, room = (uint32_t)n_idle - taken;
+                const uint32_t take = avail < room ? avail : room;
+                if (take) {
+                    wg_acquire();
+                    if (!busy && rank >= taken && rank < taken + take) {
+                        const uint32_t e = (head + (rank - taken)) & (CRT_RING_CAP - 1u);
+                        const f4 q0 = xl_ld4(base + 16u * e), q1 = xl_ld4(base + 16u * CRT_RING_CAP + 16u * e);
+                        o = mk(q0.x, q0.y, q0.z); best_t = q0.w;
+                        inv = mk(q1.x, q1.y, q1.z);
+                        const uint32_t w = __float_as_uint(q1.w);
+                        k = w & 0xfffu; pending = (w >> 12) & 0x3fffu;
+                        dst = base + 16u * (2u * CRT_RING_CAP + 1u) + 4u * (w >> 26);  // the owner lane's mailbox word
+                        exact = !finite3(inv);
+                        // finite reciprocals: sign(1/d) == sign(d), and d == -0 gives -inf (exact path, offsets unused)
+                        offx = (inv.x < 0.0f ? NL : 0u) << 4;
+                        offy = (inv.y < 0.0f ? 3u * NL : 2u * NL) << 4;
+                        offz = (inv.z < 0.0f ? 5u * NL : 4u * NL) << 4;
+                        busy = true;
+                    }
+                    taken += take;
+                    wg_release();  // the entries have been read: hand them back to the owner
+                    if (lane == 0) xl_st(ctl + 4u, head + take);
+                }
+                ow += stride;
+                if (ow >= n_owners) ow = first;
+            }
+            ++rr;
+            if (COUNT && (a.census & 1)) {  // walker census: refill attempts, requests taken, polls of a wholly idle wave
+                c_refills += 1; c_taken += taken;
+                if (taken == 0u && n_idle == 64) c_idle += 1;
+            }
+            if (taken == 0u && n_idle == 64) {
+                if (all_done) break;                    // every owner has finished: nothing can arrive any more
+                if (++idle_polls > (1u << 24)) {        // watchdog (seconds): never spin for ever on a protocol error
+                    if (lane == 0) atomicAdd(&a.counters[29], 1ull);
+                    break;
+                }
+                for (int i = 0; i < a.owner_sleep; ++i) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+                continue;
+            }
+            idle_polls = 0;
+            backoff = taken == 0u ? a.walker_backoff : 0;
+        }
+        // a thin wave (fewer than min_busy rays on board) waits a little for more requests instead of spending a whole
+        // wave-step on a few lanes -- but only `patience` polls in a row, the rays on board must get on
+        if (a.walker_min_busy > 0) {
+            const int n_busy = __popcll(__ballot(busy));
+            if (n_busy < a.walker_min_busy && patience > 0) {
+                --patience;
+                backoff = 0;
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            patience = a.walker_patience;
+        }
+        if (COUNT && (a.census & 1)) {  // walking steps and the lanes they serve
+            c_steps += 1; c_busy += (unsigned long long)__popcll(__ballot(busy));
+        }
+        if (busy) {
+            if (COUNT) n_pairs += 1;
+            bool hitL, hitR;
+            if (__builtin_expect(exact, 0)) {
+                const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+                hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, o, inv, tmin, best_t);
+                hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, o, inv, tmin, best_t);
+                hitL = hitL & (__float_as_int(q3.x) != CRT_TAG_EMPTY);
+                hitR = hitR & (__float_as_int(q3.y) != CRT_TAG_EMPTY);
+            } else {
+                const char* planes = (const char*)ws.axes;
+                const float4 ax = *(const float4*)(planes + ((k << 4) + offx));
+                const float4 ay = *(const float4*)(planes + ((k << 4) + offy));
+                const float4 az = *(const float4*)(planes + ((k << 4) + offz));
+#if CRT_FAST
+                const v3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+                const float nLx = __builtin_fmaf(ax.x, inv.x, noi.x), fLx = __builtin_fmaf(ax.y, inv.x, noi.x);
+                const float nRx = __builtin_fmaf(ax.z, inv.x, noi.x), fRx = __builtin_fmaf(ax.w, inv.x, noi.x);
+                const float nLy = __builtin_fmaf(ay.x, inv.y, noi.y), fLy = __builtin_fmaf(ay.y, inv.y, noi.y);
+                const float nRy = __builtin_fmaf(ay.z, inv.y, noi.y), fRy = __builtin_fmaf(ay.w, inv.y, noi.y);
+                const float nLz = __builtin_fmaf(az.x, inv.z, noi.z), fLz = __builtin_fmaf(az.y, inv.z, noi.z);
+                const float nRz = __builtin_fmaf(az.z, inv.z, noi.z), fRz = __builtin_fmaf(az.w, inv.z, noi.z);
+#else
+                const float nLx = (ax.x - o.x) * inv.x, fLx = (ax.y - o.x) * inv.x;
+                const float nRx = (ax.z - o.x) * inv.x, fRx = (ax.w - o.x) * inv.x;
+                const float nLy = (ay.x - o.y) * inv.y, fLy = (ay.y - o.y) * inv.y;
+                const float nRy = (ay.z - o.y) * inv.y, fRy = (ay.w - o.y) * inv.y;
+                const float nLz = (az.x - o.z) * inv.z, fLz = (az.y - o.z) * inv.z;
+                const float nRz = (az.z - o.z) * inv.z, fRz = (az.w - o.z) * inv.z;
+#endif
+                const float loL = fmaxf(fmaxf(fmaxf(nLx, nLy), nLz), tmin), hiL = fminf(fminf(fminf(fLx, fLy), fLz), best_t);
+                const float loR = fmaxf(fmaxf(fmaxf(nRx, nRy), nRz), tmin), hiR = fminf(fminf(fminf(fRx, fRy), fRz), best_t);
+                hitL = !(hiL <= loL);
+                hitR = !(hiR <= loR);
+            }
+            const bool both = hitL && hitR, any = hitL || hitR;
+            const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
+            const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
+            const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
+            k = any ? kd : kp;
+            pending = any ? pd : pp;
+            if (!((k - 1u) < (NL - 1u))) {  // a leaf to test, or the traversal is over: back to the owner lane
+                xl_st(dst, CRT_MBOX_VALID | k | (pending << 12));
+                busy = false;
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (COUNT && (a.census & 1) && lane == 0) {  // (summed in registers: atomics inside the polling loops would serialise the launch)
+        atomicAdd(&a.counters[0], c_refills); atomicAdd(&a.counters[1], c_taken); atomicAdd(&a.counters[2], c_idle);
+        atomicAdd(&a.counters[11], c_steps); atomicAdd(&a.counters[12], c_busy);
+    }
+}
+
+template <bool IN_LDS, bool COUNT, bool PERSIST, int ROLE = 0>
 __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, const walk_scene& ws, const float4* spheres,
                                                     const float4* mats, const wg_pool& pool, uint32_t& n_rays,
-                                                    uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests) {
+                                                    uint32_t& n_samples, uint32_t& n_pairs, uint32_t& n_tests,
+                                                    const owner_link link = owner_link{0, 0, 0, 0}) {
     const float tmin = 0.001f;
     const float4* pairs = ws.pairs;
     const uint32_t NL = ws.L;
@@ -561,6 +768,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
     uint32_t k = 0, pending = 0, slot = 0;
     uint32_t offx = 0, offy = 0, offz = 0;  // IN_LDS: byte offset of this ray's plane arrays (+ base)
     bool fresh = true, exact = false, finished = false;
+    bool out = false;          // ROLE 1 (owner): this lane's ray is with a walker (posted, answer not yet collected)
+    uint32_t ring_tail = 0;    // ROLE 1: the owner's own copy of its ring's tail (it is the only writer)
+    uint32_t wait_polls = 0;   // ROLE 1: watchdog, consecutive polls without anything to do
+    unsigned long long c_waits = 0;  // ROLE 1 census: scheduler iterations that found too little to do
     uint32_t* ust = (uint32_t*)(pool.acc + 192);  // PERSIST: the wave's unit state, behind its accumulators
     // census (COUNT && a.census): shader cycles of this wave per phase, counters[16..21]
     const bool timing = COUNT && (a.census & 2);
@@ -580,6 +791,34 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       // its registers across it (no copies at the loop's merge points).
       int phase = -1;
       for (;;) {
+        if (ROLE == 1) {
+            // collect: a lane whose ray is out reads its mailbox word
+            if (out) {
+                const uint32_t v = xl_ld(link.mbox + 4u * (uint32_t)lane);
+                if (v & CRT_MBOX_VALID) {
+                    k = v & 0xfffu; pending = (v >> 12) & 0x3ffffu; out = false;
+                    xl_st(link.mbox + 4u * (uint32_t)lane, 0u);
+                }
+            }
+            // post: rays with boxes to walk go into the ring (as many as it has room for; the rest try again)
+            const bool want = !out && ((k - 1u) < (NL - 1u));
+            const unsigned long long m_post = __ballot(want);
+            if (m_post != 0) {
+                const uint32_t head = uniform(xl_ld(link.ctl + 4u));
+                const uint32_t room = CRT_RING_CAP - (uniform(ring_tail) - head);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_post >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_post, 0u));
+                if (want && rank < room) {
+                    const uint32_t e = (uniform(ring_tail) + rank) & (CRT_RING_CAP - 1u);
+                    xl_st4(link.q0 + 16u * e, f4{p.r.o.x, p.r.o.y, p.r.o.z, best_t});
+                    xl_st4(link.q1 + 16u * e, f4{inv.x, inv.y, inv.z, __uint_as_float(k | (pending << 12) | ((uint32_t)lane << 26))});
+                    out = true;
+                }
+                const uint32_t n_post = (uint32_t)__popcll(m_post);
+                ring_tail = uniform(ring_tail) + (n_post < room ? n_post : room);
+                wg_release();  // entries before the tail
+                if (lane == __builtin_ctzll(m_post)) xl_st(link.ctl, ring_tail);
+            }
+        }
         const unsigned long long m_run = __ballot((k - 1u) < (NL - 1u));
         const unsigned long long m_leaf = __ballot(k >= NL);
         const unsigned long long m_shade = __ballot((k == 0u) & !finished);
@@ -591,7 +830,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         else if (n_shade * 16 >= alive * a.shade_num && n_shade > 0) ph = ST_SHADE;
         else if (n_run > 0) ph = ST_RUN;
         else ph = (n_leaf >= n_shade) ? ST_LEAF : ST_SHADE;
-        if (COUNT && (a.census & 1) && lane == 0) {  // scheduler census: iterations and served lanes per phase
+        if (COUNT && (a.census & 1) && ROLE == 1 && ph == ST_RUN) c_waits += 1;  // (owner waiting: counted in a register)
+        else if (COUNT && (a.census & 1) && lane == 0) {  // scheduler census: iterations and served lanes per phase
             const int served = ph == ST_RUN ? n_run : ph == ST_LEAF ? n_leaf : n_shade;
             atomicAdd(&a.counters[4 + 2 * ph], 1ull);
             atomicAdd(&a.counters[5 + 2 * ph], (unsigned long long)served);
@@ -599,7 +839,15 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         }
         CRT_LAP(0);
         if (ph == ST_SHADE) { phase = ph; break; }
-        if (ph == ST_RUN) {
+        if (ROLE == 1 && ph == ST_RUN) {
+            // owner: the rays are with the walkers and too few lanes wait for the sphere or shade phase -- wait
+            if (++wait_polls > (1u << 24)) {  // watchdog (seconds): never spin for ever on a protocol error
+                if (lane == 0) atomicAdd(&a.counters[29], 1ull);
+                k = 0u; finished = true; out = false;
+            }
+            for (int i = 0; i < a.owner_sleep; ++i) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+            CRT_LAP(1);
+        } else if (ROLE != 1 && ph == ST_RUN) {
             // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
             const int leave_at = n_run - max(1, n_run >> a.run_shift);
             bool walking = (k - 1u) < (NL - 1u);
@@ -683,6 +931,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             }
             CRT_LAP(1);
         } else {
+            if (ROLE == 1) wait_polls = 0;
             if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
                 int2 tg;
@@ -707,6 +956,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         }
       }
       if (phase < 0) break;
+      if (ROLE == 1) wait_polls = 0;
       {
         {
             // The shade phase has three parts: (1) hit record / next work item, lanes in the shade
@@ -988,6 +1238,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       }
     }
     if (PERSIST && (uniform(ust_ld(ust, U_FLAGS)) & 1u)) unit_flush(a, pool.acc, ust, lane);
+    if (ROLE == 1 && lane == 0) xl_st(link.ctl + 8u, 1u);  // tells this owner's walker that nothing more will be posted
+    if (ROLE == 1 && COUNT && (a.census & 1) && lane == 0) atomicAdd(&a.counters[3], c_waits);
     if (timing && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&a.counters[16 + i], tc[i]);
         const unsigned long long t = wall_clock64();
@@ -1000,7 +1252,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
 
 // ---------------------------------------------------------------------------------------
 // SCHED: 0 = simple per-lane loop, 1 = wave-scheduled with a workgroup item pool, 2 = wave-scheduled
-// persistent waves
+// persistent waves, 3 = persistent owner waves + walker waves exchanging walk requests through LDS rings
 template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK, int SCHED>
 __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) {
     extern __shared__ float4 smem[];
@@ -1058,6 +1310,27 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
         wg_pool pool;
         pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0;
         trace_bvh_scheduled<IN_LDS, COUNT, true>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests);
+    } else if (WORLD == 1 && SCHED == 3 && IN_LDS) {
+        // walker / owner waves (see walker_loop): the first n_walkers waves walk, the others own the paths
+        const int n_walk = a.n_walkers, n_own = NW - n_walk;
+        float4* xb = smem + np + nsph + 130 * n_own;  // behind the owners' accumulator areas (260 u64 = 130 float4 each)
+        for (int i = threadIdx.x; i < n_own * (int)CRT_XCHG_FLOAT4_PER_OWNER; i += BLOCK) xb[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        unsigned long long* acc = (unsigned long long*)(smem + np + nsph) + 260 * (wave >= n_walk ? wave - n_walk : 0);
+        if (wave >= n_walk)
+            for (int i = lane; i < 260; i += 64) acc[i] = 0ull;
+        __syncthreads();  // scene image, rings and mailboxes are set up; from here on only the exchange protocol orders the waves
+        if (wave < n_walk) {
+            walker_loop<COUNT>(a, ws, lds_off(xb), (uint32_t)wave, (uint32_t)n_walk, (uint32_t)n_own, n_pairs);
+        } else {
+            owner_link link;
+            link.q0 = lds_off(xb) + (uint32_t)(wave - n_walk) * (16u * CRT_XCHG_FLOAT4_PER_OWNER);
+            link.q1 = link.q0 + 16u * CRT_RING_CAP;
+            link.ctl = link.q0 + 32u * CRT_RING_CAP;
+            link.mbox = link.ctl + 16u;
+            wg_pool pool;
+            pool.acc = acc; pool.counter = nullptr; pool.origin = nullptr; pool.shift = 6; pool.total = 0;
+            trace_bvh_scheduled<IN_LDS, COUNT, true, 1>(a, ws, spheres, mats, pool, n_rays, n_samples, n_pairs, n_tests, link);
+        }
     } else if (WORLD == 1 && SCHED == 1) {
         const int T = a.tiles_per_wg;  // power of two
         unsigned long long* acc = (unsigned long long*)(smem + np + nsph);
@@ -1141,7 +1414,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(const crt_render_args a) 
     {
         const uint32_t r = wave_sum(n_rays), sm = wave_sum(n_samples);
         // (the persistent kernel's 6144 waves finish spread over the launch's drain: one stripe, and its code stays as tuned)
-        unsigned long long* stats = a.counters + CRT_STATS_BASE + (SCHED == 2 ? 0 : 4 * (blockIdx.x & (CRT_STAT_STRIPES - 1)));
+        unsigned long long* stats = a.counters + CRT_STATS_BASE + (SCHED >= 2 ? 0 : 4 * (blockIdx.x & (CRT_STAT_STRIPES - 1)));
         if (lane == 0 && r) { atomicAdd(&stats[0], (unsigned long long)r); atomicAdd(&stats[1], (unsigned long long)sm); }
         if (COUNT) {
             const uint32_t pv = wave_sum(n_pairs), stt = wave_sum(n_tests);
@@ -1216,6 +1489,8 @@ hipError_t launch_sched(const crt_render_args& a, int grid, size_t lds_bytes, hi
 
 template <int WORLD, bool IN_LDS, bool COUNT, int BLOCK>
 hipError_t launch_one(const crt_render_args& a, int grid, size_t lds_bytes, hipStream_t stream) {
+    if (WORLD == 1 && IN_LDS && a.sched == 3 && a.persist && (BLOCK == 768 || BLOCK == 1024))
+        return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1 && IN_LDS && (BLOCK == 768 || BLOCK == 1024) ? 3 : 0)>(a, grid, lds_bytes, stream);
     if (WORLD == 1 && a.sched && a.persist) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1 ? 2 : 0)>(a, grid, lds_bytes, stream);
     if (WORLD == 1 && a.sched) return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, (WORLD == 1 ? 1 : 0)>(a, grid, lds_bytes, stream);
     return launch_sched<WORLD, IN_LDS, COUNT, BLOCK, 0>(a, grid, lds_bytes, stream);

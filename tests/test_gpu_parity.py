@@ -174,7 +174,12 @@ def test_golden_paths_and_c1_frame(crt):
                                  dict(CRT_UNIT_SAMPLES=16, CRT_UNIT_FINE=5, CRT_UNIT_FINE_PCT=100), dict(CRT_TAIL_PASS=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=0), dict(CRT_LDS_LIMIT=0, CRT_TOP_PAIRS=64),
                                  dict(CRT_BLOCK=256), dict(CRT_BLOCK=1024), dict(CRT_LDS_LIMIT=0),
                                  dict(CRT_LEAF_NUM=1, CRT_SHADE_NUM=1, CRT_RUN_SHIFT=6),
-                                 dict(CRT_LEAF_NUM=16, CRT_SHADE_NUM=16, CRT_RUN_SHIFT=0)])
+                                 dict(CRT_LEAF_NUM=16, CRT_SHADE_NUM=16, CRT_RUN_SHIFT=0),
+                                 # SCHED=3: walker waves + owner waves exchanging walk requests through LDS rings
+                                 dict(CRT_SCHED=3), dict(CRT_SCHED=3, CRT_WALKERS=2, CRT_REFILL_MIN=1),
+                                 dict(CRT_SCHED=3, CRT_BLOCK=1024, CRT_WALKERS=6, CRT_REFILL_MIN=64),
+                                 dict(CRT_SCHED=3, CRT_WALKERS=1, CRT_OWNER_SLEEP=0, CRT_LEAF_NUM=1, CRT_SHADE_NUM=1),
+                                 dict(CRT_SCHED=3, CRT_WALKERS=8, CRT_UNIT_SAMPLES=3, CRT_TAIL_PASS=0)])
 def test_image_independent_of_launch_geometry(crt, orc, rnd, env):
     """Random-spheres scene through the BVH at a ragged size (97x54, 67 spp): every kernel variant,
     workgroup shape and scheduler setting gives the oracle's frame bit for bit."""
@@ -186,6 +191,8 @@ def test_image_independent_of_launch_geometry(crt, orc, rnd, env):
     sums, ost = orc.render(osc, ocam, seed, 0, spp, 50, onodes, nthreads=8)
     assert _bits_equal(fb, orc.resolve(sums, spp))
     assert st.rays == ost[0] and st.samples == ost[3]
+    if env.get("CRT_SCHED") == 3:
+        assert "SCHED=3" in r.kernel_name()
     r.close()
 
 

@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401
 
 import cuda_ray_tracer_amd as crt  # noqa: E402
 
-KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_ARITH")
+KNOBS = ("CRT_BLOCK", "CRT_TILES", "CRT_SCHED", "CRT_LEAF_NUM", "CRT_SHADE_NUM", "CRT_LDS_LIMIT", "CRT_RUN_SHIFT", "CRT_PERSIST", "CRT_UNIT_SAMPLES", "CRT_TAIL_PASS", "CRT_TOP_PAIRS", "CRT_UNIT_FINE", "CRT_UNIT_FINE_PCT", "CRT_ARITH", "CRT_WALKERS", "CRT_REFILL_MIN", "CRT_OWNER_SLEEP", "CRT_WALKER_BACKOFF", "CRT_WALKER_PRIO", "CRT_WALKER_MIN_BUSY", "CRT_WALKER_PATIENCE")
 
 
 def make(variant, args):
@@ -79,6 +79,8 @@ def main():
             msg += f" RUN steps {c[11]} ({c[11] / st.rays:.3f}/ray) lanes still walking after a step {c[12] / max(1, c[11]):.1f};"
             msg += f" Philox loop iters {c[13]} ({c[13] / max(1, c[8]):.2f}/shade phase) lanes/iter {c[14] / max(1, c[13]):.1f};"
             msg += f" alive/iter {c[10] / max(1, c[4] + c[6] + c[8]):.1f}"
+            if c[0]:  # SCHED=3 walkers: refill attempts, requests per attempt, polls of a wholly idle walker; watchdog
+                msg += f" WALKER refills {c[0]} ({c[1] / c[0]:.2f} requests each) idle polls {c[2]} owner waits {c[3]} watchdog {c[29]};"
             r.set_count_stats(3)  # per-phase shader cycles only (no per-iteration atomics)
             buf.zero_()
             r.render_accumulate(crt.CRT_WORLD_BVH, 0, args.spp, args.depth, buf.data_ptr(), 0)
