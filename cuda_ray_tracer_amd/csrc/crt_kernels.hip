@@ -246,6 +246,68 @@ __device__ __forceinline__ bool slab_fast(float bx0, float bx1, float by0, float
 }
 
 
+// slab_fast's two interval ends (the caller compares them: successor_lohi)
+__device__ __forceinline__ void slab_lohi(float bx0, float bx1, float by0, float by1, float bz0, float bz1, v3 o,
+                                          v3 inv, v3 noi, float lo, float hi, float& lo_out, float& hi_out) {
+#if CRT_FAST
+    const float tx0 = __builtin_fmaf(bx0, inv.x, noi.x), tx1 = __builtin_fmaf(bx1, inv.x, noi.x);
+    const float ty0 = __builtin_fmaf(by0, inv.y, noi.y), ty1 = __builtin_fmaf(by1, inv.y, noi.y);
+    const float tz0 = __builtin_fmaf(bz0, inv.z, noi.z), tz1 = __builtin_fmaf(bz1, inv.z, noi.z);
+#else
+    const float tx0 = (bx0 - o.x) * inv.x, tx1 = (bx1 - o.x) * inv.x;
+    const float ty0 = (by0 - o.y) * inv.y, ty1 = (by1 - o.y) * inv.y;
+    const float tz0 = (bz0 - o.z) * inv.z, tz1 = (bz1 - o.z) * inv.z;
+#endif
+    lo = fmaxf(lo, fminf(tx0, tx1)); hi = fminf(hi, fmaxf(tx0, tx1));
+    lo = fmaxf(lo, fminf(ty0, ty1)); hi = fminf(hi, fmaxf(ty0, ty1));
+    lo = fmaxf(lo, fminf(tz0, tz1)); hi = fminf(hi, fmaxf(tz0, tz1));
+    lo_out = lo; hi_out = hi;
+}
+
+// Successor of a traversal step (helper_experimental.h:28-45 over the implicit heap): descend -- left child first, the
+// right one remembered in `pending` when both were hit -- or pop the nearest pending right sibling.
+__device__ __forceinline__ void successor(uint32_t& k, uint32_t& pending, bool hitL, bool hitR) {
+    const bool both = hitL && hitR, any = hitL || hitR;
+    const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
+    const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
+    const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
+    k = any ? kd : kp;
+    pending = any ? pd : pp;
+}
+
+// The same successor from the interval ends of the two children (child hit <=> !(hi <= lo)), hand-scheduled: the
+// compiler's form spends 13 vector instructions on it (two compares, two 0/1 materialisations, two shift-ors, ctz,
+// two shifts, two xors, two selects); this one 9 -- the descent is k + k + carry (v_addc_co_u32 with the lane masks
+// "left missed" / "both hit" as carry-in) and the select is done by the EXEC mask, which is restored before the block
+// ends.  k and pending are updated in place.  Identical results to successor() for every input (tests).
+__device__ __forceinline__ void successor_lohi(uint32_t& k, uint32_t& pending, float loL, float hiL, float loR, float hiR) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CRT_SUCCESSOR_PLAIN)
+    uint32_t t0, t1;
+    unsigned long long mL, mR, m_any, saved;
+    asm("v_ffbl_b32 %[t0], %[p]\n\t"
+        "v_cmp_nle_f32 %[mL], %[hiL], %[loL]\n\t"
+        "v_cmp_nle_f32 %[mR], %[hiR], %[loR]\n\t"
+        "v_lshrrev_b32 %[t1], %[t0], %[k]\n\t"
+        "v_lshrrev_b32 %[t0], %[t0], %[p]\n\t"
+        "s_or_b64 %[any], %[mL], %[mR]\n\t"
+        "s_and_b64 %[mR], %[mL], %[mR]\n\t"
+        "s_not_b64 %[mL], %[mL]\n\t"
+        "s_and_saveexec_b64 %[sv], %[any]\n\t"          // lanes that descend
+        "v_addc_co_u32 %[k], vcc, %[k], %[k], %[mL]\n\t"  // 2k + (left missed)
+        "v_addc_co_u32 %[p], vcc, %[p], %[p], %[mR]\n\t"  // 2 pending + (both hit)
+        "s_andn2_b64 exec, %[sv], %[any]\n\t"           // lanes that pop
+        "v_xor_b32 %[k], 1, %[t1]\n\t"
+        "v_xor_b32 %[p], 1, %[t0]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [k] "+v"(k), [p] "+v"(pending), [t0] "=&v"(t0), [t1] "=&v"(t1), [mL] "=&s"(mL), [mR] "=&s"(mR),
+          [any] "=&s"(m_any), [sv] "=&s"(saved)
+        : [loL] "v"(loL), [hiL] "v"(hiL), [loR] "v"(loR), [hiR] "v"(hiR)
+        : "vcc");
+#else
+    successor(k, pending, !(hiL <= loL), !(hiR <= loR));
+#endif
+}
+
 __device__ __forceinline__ bool finite3(v3 a) {
     return (fabsf(a.x) < __builtin_huge_valf()) & (fabsf(a.y) < __builtin_huge_valf()) & (fabsf(a.z) < __builtin_huge_valf());
 }
@@ -850,19 +912,29 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         } else if (ROLE != 1 && ph == ST_RUN) {
             // stay in the box-walking loop until enough lanes have left it to be worth re-scheduling
             const int leave_at = n_run - max(1, n_run >> a.run_shift);
-            bool walking = (k - 1u) < (NL - 1u);
-            for (;;) {
-                if (walking) {
+            // Rays with a non-finite reciprocal (a zero or denormal direction component: rare) take the literal
+            // comparisons of aabb.h:48-62 on the HBM records, HERE, until they reach a leaf or finish -- so the hot
+            // loop below carries no branch for them (6 scalar instructions per step less).
+            if (__ballot(exact && ((k - 1u) < (NL - 1u))) != 0) {
+                while (exact && ((k - 1u) < (NL - 1u))) {
                     if (COUNT) n_pairs += 1;
-                    bool hitL, hitR;
-                    if (__builtin_expect(exact, 0)) {
-                        // a zero/denormal direction component: the literal comparisons of aabb.h:48-62
-                        const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
-                        hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
-                        hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
-                        hitL = hitL & (__float_as_int(q3.x) != CRT_TAG_EMPTY);
-                        hitR = hitR & (__float_as_int(q3.y) != CRT_TAG_EMPTY);
-                    } else if (IN_LDS) {
+                    const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+                    bool hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
+                    bool hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
+                    hitL = hitL & (__float_as_int(q3.x) != CRT_TAG_EMPTY);
+                    hitR = hitR & (__float_as_int(q3.y) != CRT_TAG_EMPTY);
+                    successor(k, pending, hitL, hitR);
+                }
+            }
+            // (the set of walking lanes is carried round the loop as a lane MASK in scalar registers and turned back
+            // into the branch condition for free; carried as a boolean it cost three scalar mask merges per step)
+            unsigned long long m_walk = __ballot((k - 1u) < (NL - 1u));
+            for (;;) {
+                if (COUNT && (a.census & 1) && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)__popcll(m_walk)); }
+                if (__builtin_amdgcn_inverse_ballot_w64(m_walk)) {
+                    if (COUNT) n_pairs += 1;
+                    float loL, hiL, loR, hiR;
+                    if (IN_LDS) {
                         // empty children carry a far-away degenerate box (crt_api.cpp): near == far on
                         // every axis, so max(near) >= min(far) and the test rejects them by itself
                         const char* planes = (const char*)ws.axes;
@@ -888,10 +960,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const float nLz = (az.x - p.r.o.z) * inv.z, fLz = (az.y - p.r.o.z) * inv.z;
                         const float nRz = (az.z - p.r.o.z) * inv.z, fRz = (az.w - p.r.o.z) * inv.z;
 #endif
-                        const float loL = fmaxf(fmaxf(fmaxf(nLx, nLy), nLz), tmin), hiL = fminf(fminf(fminf(fLx, fLy), fLz), best_t);
-                        const float loR = fmaxf(fmaxf(fmaxf(nRx, nRy), nRz), tmin), hiR = fminf(fminf(fminf(fRx, fRy), fRz), best_t);
-                        hitL = !(hiL <= loL);
-                        hitR = !(hiR <= loR);
+                        loL = fmaxf(fmaxf(fmaxf(nLx, nLy), nLz), tmin); hiL = fminf(fminf(fminf(fLx, fLy), fLz), best_t);
+                        loR = fmaxf(fmaxf(fmaxf(nRx, nRy), nRz), tmin); hiR = fminf(fminf(fminf(fRx, fRy), fRz), best_t);
                     } else {
                         // scene in HBM: the upper levels of the tree (every ray walks them) come from LDS,
                         // which halves the L1 traffic that bounds this instance
@@ -912,22 +982,15 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         q0 = q1 = q2 = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
 #endif
                         const v3 noi = mk(-(p.r.o.x * inv.x), -(p.r.o.y * inv.y), -(p.r.o.z * inv.z));  // CRT_FAST only (dead otherwise)
-                        hitL = slab_fast(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, noi, tmin, best_t);
-                        hitR = slab_fast(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, noi, tmin, best_t);
+                        slab_lohi(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, noi, tmin, best_t, loL, hiL);
+                        slab_lohi(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, noi, tmin, best_t, loR, hiR);
                     }
                     // branch-free successor: descend (left first, right remembered) -- onto a leaf:
                     // hold it for the sphere phase -- or pop the nearest pending right sibling
-                    const bool both = hitL && hitR, any = hitL || hitR;
-                    const uint32_t kd = (k << 1) | (hitL ? 0u : 1u), pd = (pending << 1) | (both ? 1u : 0u);
-                    const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
-                    const uint32_t kp = (k >> up) ^ 1u, pp = (pending >> up) ^ 1u;
-                    k = any ? kd : kp;
-                    pending = any ? pd : pp;
+                    successor_lohi(k, pending, loL, hiL, loR, hiR);
                 }
-                walking = (k - 1u) < (NL - 1u);
-                const int still = __popcll(__ballot(walking));
-                if (COUNT && (a.census & 1) && lane == 0) { atomicAdd(&a.counters[11], 1ull); atomicAdd(&a.counters[12], (unsigned long long)still); }
-                if (still <= leave_at) break;
+                m_walk = __ballot((k - 1u) < (NL - 1u));
+                if (__popcll(m_walk) <= leave_at) break;
             }
             CRT_LAP(1);
         } else {

@@ -76,7 +76,7 @@ def main():
             c = list(c)
             names = ["RUN", "LEAF", "SHADE"]
             msg = " ".join(f"{names[j]}: iters {c[4 + 2 * j]} lanes/iter {c[5 + 2 * j] / max(1, c[4 + 2 * j]):.1f}" for j in range(3))
-            msg += f" RUN steps {c[11]} ({c[11] / st.rays:.3f}/ray) lanes still walking after a step {c[12] / max(1, c[11]):.1f};"
+            msg += f" RUN steps {c[11]} ({c[11] / st.rays:.3f}/ray) lanes per walking step {c[12] / max(1, c[11]):.1f};"
             msg += f" Philox loop iters {c[13]} ({c[13] / max(1, c[8]):.2f}/shade phase) lanes/iter {c[14] / max(1, c[13]):.1f};"
             msg += f" alive/iter {c[10] / max(1, c[4] + c[6] + c[8]):.1f}"
             if c[0]:  # SCHED=3 walkers: refill attempts, requests per attempt, polls of a wholly idle walker; watchdog
