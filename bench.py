@@ -16,6 +16,7 @@ Metric: Mrays/s, whole job; one ray = one closest-hit query of the bounce loop
       --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -61,6 +62,15 @@ def parse_args(argv=None):
                          "bit-identical to the CPU oracle) or fast (fma slab test + contraction; within the tolerance of "
                          "tests/test_gpu_round2.py::test_fast_arithmetic_within_stated_tolerance).  The other mode is measured "
                          "beside it, untimed by the step clock (HIP events)")
+    ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
+                    help="double-buffered steps: two contexts, two sums buffers and two streams per rank, so that the reduce + "
+                         "resolve of image k run behind the trace of image k+1 and the next launch's workgroups start in the "
+                         "drain tail of the previous one (DESIGN.md 5).  auto = on for N > 1 (and the one-GPU rehearsals of "
+                         "the N-rank path), off for N = 1: the driver's single-GPU line renders its steps strictly one after "
+                         "the other.  time_to_image_ms is always the un-pipelined figure")
+    ap.add_argument("--verify-steps", action="store_true",
+                    help="read every timed step's frame back and report its SHA-256 (step_frame_sha256; tests/test_gpu_rccl.py) "
+                         "-- the read-backs synchronise, so the timings of such a run mean nothing")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the RCCL process group and issue every collective of the "
                          "N > 1 path (one-GPU rehearsal, tests/test_gpu_rccl.py)")
@@ -211,6 +221,8 @@ class GpuRank:
         self.stream = torch.cuda.current_stream().cuda_stream
         self.depth = args.depth
         self.backend = "gloo" if args.share_gpu else "nccl"
+        self.args = args
+        self.slots = []
 
     def trace(self, first, count, tile_stride=1, tile_offset=0):
         self.r.render_accumulate(self.world, first, count, self.depth, self.sums.data_ptr(), self.stream,
@@ -219,11 +231,45 @@ class GpuRank:
     def resolve(self, spp):
         self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.stream)
 
+    def make_slots(self):
+        """Two (context, sums, frame, stream) sets for double-buffered steps: launches that overlap on the GPU need a
+        context each (include/crt_hip.h), and each set works on a stream of its own."""
+        torch, crt = self.torch, self.crt
+        for i in range(2):
+            slot = GpuSlot()
+            if i == 0:
+                slot.r, slot.sums, slot.frame = self.r, self.sums, self.frame
+            else:
+                slot.r = crt.Renderer(self.dev.index, self.args.seed)
+                slot.r.set_arith(crt.CRT_ARITH_FAST if self.args.arith == "fast" else crt.CRT_ARITH_EXACT)
+                slot.r.upload_scene(self.scene)
+                slot.r.build_bvh(17)
+                slot.r.set_camera(self.cam)
+                slot.sums = torch.zeros_like(self.sums)
+                slot.frame = torch.empty_like(self.frame)
+            slot.tstream = torch.cuda.Stream(device=self.dev)
+            slot.stream = slot.tstream.cuda_stream
+            slot.world, slot.depth = self.world, self.depth
+            self.slots.append(slot)
+        torch.cuda.synchronize()
+        return self.slots
+
     def sync(self):
         self.torch.cuda.synchronize()
 
     def close(self):
+        for slot in self.slots[1:]:
+            slot.r.close()
         self.r.close()
+
+
+class GpuSlot:
+    def trace(self, first, count, tile_stride=1, tile_offset=0):
+        self.r.render_accumulate(self.world, first, count, self.depth, self.sums.data_ptr(), self.stream,
+                                 tile_stride=tile_stride, tile_offset=tile_offset)
+
+    def resolve(self, spp):
+        self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.stream)
 
 
 class RehearsalRank:
@@ -250,6 +296,15 @@ class RehearsalRank:
 
     def resolve(self, spp):
         self.frame.copy_((self.sums.to(self.torch.float64) * (2.0 ** -40 / spp)).to(self.torch.float32))
+
+    def make_slots(self):
+        """CPU stand-in of GpuRank.make_slots: two sets of buffers, no streams."""
+        import copy
+        self.tstream = None
+        other = copy.copy(self)
+        other.sums, other.frame = self.torch.zeros_like(self.sums), self.torch.empty_like(self.frame)
+        self.slots = [self, other]
+        return self.slots
 
     def sync(self):
         pass
@@ -318,17 +373,42 @@ def main():
         if rank == 0:
             g.resolve(args.spp)
 
+    # Double-buffered steps (N > 1): image k on slot k % 2 -- its own context, sums, frame and stream.  The zeroing, the
+    # trace, the reduce (torch orders the collective behind the CURRENT stream and the current stream behind the
+    # collective) and the resolve of image k are ordered on slot k % 2's stream; image k+1 runs on the other stream, so
+    # its trace fills the chip while image k drains, reduces and resolves.  A slot is reused two images later, behind
+    # its own previous resolve.  The frames are the un-pipelined frames bit for bit (integer sums).
+    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and use_dist)
+    if passes > 1:
+        pipelined = False
+    slots = g.make_slots() if pipelined else []
+    step_hashes = []
+
+    def step_pipelined(k):
+        sl = slots[k % 2]
+        ctx = torch.cuda.stream(sl.tstream) if getattr(sl, "tstream", None) is not None else contextlib.nullcontext()
+        with ctx:
+            render_split(sl.trace, sl.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split,
+                         host_staged=args.share_gpu)
+            if rank == 0:
+                sl.resolve(args.spp)
+                if args.verify_steps:
+                    step_hashes.append(hashlib.sha256(sl.frame.cpu().numpy().tobytes()).hexdigest())
+
     def sync():
         if use_dist:
             dist.barrier()
         g.sync()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step_pipelined(k) if pipelined else step()
     sync()
+    step_hashes.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step_pipelined(args.warmup + k) if pipelined else step()
+        if args.verify_steps and not pipelined and rank == 0:
+            step_hashes.append(hashlib.sha256(g.frame.cpu().numpy().tobytes()).hexdigest())
     g.sync()
     if use_dist:
         dist.barrier()
@@ -336,14 +416,19 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_s = []
     if args.rehearse_cpu:
-        rays_rank, samples_rank = (float(v) for v in g.last)
+        rays_rank, samples_rank = (float(v) for v in max(sl.last for sl in (slots or [g])))
     else:
         st = g.r.stats() if has_work else None  # last launch: rays of one step on this rank (identical every step)
         rays_rank = float(st.rays) if st else 0.0
         samples_rank = float(st.samples) if st else 0.0
         # per-launch kernel time of the TIMED steps: HIP events the library records on the launch
         # stream around every launch (it keeps the last 64)
-        if has_work and args.steps > 0:
+        if has_work and args.steps > 0 and pipelined:  # the timed launches are spread over the two contexts
+            for i, sl in enumerate(slots):
+                mine = len([k for k in range(args.warmup, args.warmup + args.steps) if k % 2 == i])
+                if mine:
+                    kernel_s += sl.r.kernel_times(min(mine, 64))
+        elif has_work and args.steps > 0:
             kernel_s = g.r.kernel_times(min(args.steps * passes, 64))
         if has_work and passes > 1:  # rays of one image = the sum over its passes: one more, untimed, image with a read-back per pass
             g.sums.zero_()
@@ -387,7 +472,10 @@ def main():
             "hip_runtime_init_ms": g.t_hip * 1e3, "context_ms": g.t_ctx * 1e3, "scene_generation_ms": g.t_scene * 1e3, "bvh_build_ms": g.t_bvh * 1e3,
             "image_mean": float(img.mean()),
             "frame_sha256": hashlib.sha256(img.numpy().tobytes()).hexdigest(),
+            "pipelined": bool(pipelined),
         }
+        if args.verify_steps:
+            out["step_frame_sha256"] = step_hashes
         if not args.rehearse_cpu:
             gpu_report(args, g, out, share, kernel_s, world_size, np)
         print(json.dumps(out), flush=True)

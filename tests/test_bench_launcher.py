@@ -43,6 +43,16 @@ def test_control_flow_rehearsal(gpus, split):
     assert out["image_mean"] == 1.0
     assert out["rays_per_step"] == 2.0 * 72 * 40 * 7
     assert out["value"] > 0 and out["time_to_image_ms"] > 0
+    assert out["pipelined"] == (gpus > 1)  # N > 1: double-buffered steps
+
+
+def test_pipelined_control_flow_rehearsal():
+    """The double-buffered step loop on CPU tensors, 2 ranks: every timed step's frame is the complete image."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "72", "--spp", "7", "--rehearse-cpu", "--verify-steps"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["pipelined"] and len(out["step_frame_sha256"]) == 3
+    assert set(out["step_frame_sha256"]) == {out["frame_sha256"]}
 
 
 def test_missing_gpus_are_reported_by_the_ranks():

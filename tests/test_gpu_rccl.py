@@ -50,7 +50,33 @@ def test_hip_path_under_n_ranks_on_one_gpu():
     two = run(["--gpus", "2", "--share-gpu"])
     three = run(["--gpus", "3", "--share-gpu", "--split", "tiles"])
     assert two["n_gpus"] == 2 and three["n_gpus"] == 3
+    assert not one["pipelined"] and two["pipelined"] and three["pipelined"]  # N > 1: double-buffered steps by default
     for other in (two, three):
         assert other["frame_sha256"] == one["frame_sha256"]
         assert other["rays_per_step"] == one["rays_per_step"] > 0
         assert other["msamples_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_pipelined_steps_give_the_single_rank_frame_every_step():
+    """Double-buffered steps (bench.py --pipeline, the default for N > 1): image k on context / sums / stream k % 2, so the
+    reduce and resolve of image k run behind the trace of image k+1.  Every one of 5 timed steps, at 2 and 3 ranks
+    (both splits) and on one rank, must produce the frame of the plain single-rank step, bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--width", "320", "--spp", "9",
+              "--cpu-seconds", "0", "--verify-steps"]
+
+    def run(extra):
+        r = subprocess.run(common + extra, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    plain = run(["--gpus", "1", "--pipeline", "off"])
+    want = plain["frame_sha256"]
+    assert plain["step_frame_sha256"] == [want] * 5 and not plain["pipelined"]
+    for extra in (["--gpus", "1", "--pipeline", "on"], ["--gpus", "2", "--share-gpu"],
+                  ["--gpus", "3", "--share-gpu", "--split", "tiles"], ["--gpus", "1", "--force-dist"]):
+        out = run(extra)
+        assert out["pipelined"], extra
+        assert out["step_frame_sha256"] == [want] * 5, extra
+        assert out["frame_sha256"] == want and out["rays_per_step"] == plain["rays_per_step"]

@@ -44,6 +44,32 @@ def main():
             ts.append(st.kernel_seconds * 1e3)
         return statistics.median(ts[1:]), st.rays
 
+    # the same share back to back from TWO contexts alternating on two streams (bench.py's double-buffered steps for
+    # N > 1): the next launch's workgroups start in the drain tail of the previous one; ms per launch, wall clock
+    import time
+    r2 = crt.Renderer(0, 1)
+    r2.set_arith(crt.CRT_ARITH_FAST if args.arith == "fast" else crt.CRT_ARITH_EXACT)
+    r2.upload_scene(crt.scene_random(18, 11))
+    r2.build_bvh(17)
+    r2.set_camera(cam)
+    buf2 = torch.zeros_like(buf)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def piped(sh, launches=24):
+        best = 1e9
+        for _ in range(args.rounds + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(launches):
+                rr, bb, ss = ((r, buf, streams[0]), (r2, buf2, streams[1]))[k % 2]
+                with torch.cuda.stream(ss):
+                    bb.zero_()
+                    rr.render_accumulate(crt.CRT_WORLD_BVH, sh["first"], sh["nsamples"], args.depth, bb.data_ptr(), ss.cuda_stream,
+                                         tile_stride=sh["tile_stride"], tile_offset=sh["tile_offset"])
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / launches * 1e3)
+        return best
+
     full_ms, full_rays = timed(share_of_rank(args.spp, 1, 0))
     print(f"{args.width}x{cam.image_height} {args.spp} spp, arith {args.arith}: full frame {full_ms:.2f} ms, {full_rays} rays, "
           f"{full_rays / full_ms / 1e3:.0f} Mrays/s", flush=True)
@@ -56,7 +82,13 @@ def main():
             print(f"  G={G} {split:8s}: share ms min {min(ms):.2f} max {max(ms):.2f} (ideal {full_ms / G:.2f}); rays/share min {min(rays)} "
                   f"max {max(rays)} (imbalance {max(rays) / (full_rays / G) - 1:+.2%}); node rate before the combine "
                   f"{full_rays / max(ms) / 1e3:.0f} Mrays/s = {full_ms / max(ms) / G:.1%} of linear", flush=True)
+            if split == "samples":
+                g_slow = ms.index(max(ms))
+                pm = piped(share_of_rank(args.spp, G, g_slow, split))
+                print(f"  G={G} samples, double-buffered (two contexts, two streams), slowest share: {pm:.2f} ms per launch incl. "
+                      f"zeroing = {full_ms / pm / G:.1%} of linear", flush=True)
     r.close()
+    r2.close()
 
 
 if __name__ == "__main__":
