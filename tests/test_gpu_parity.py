@@ -333,7 +333,9 @@ def test_fuzz_scene_camera_depth(crt, orc, case):
               lookfrom=tuple(float(x) for x in rng.uniform([-6, 0.3, -6], [6, 3, 6])),
               lookat=tuple(float(x) for x in rng.uniform([-3, 0, -3], [3, 1, 3])))
     cam, ocam = crt.camera(W, spp, **kw), orc.camera(W, spp, **kw)
-    r = _renderer(crt, sc, cam, 77 + case)
+    # CRT_FUZZ_ENV="CRT_SCHED=3 CRT_WALKERS=3": the campaign under other launch knobs (profiles/ records such runs)
+    fuzz_env = dict(kv.split("=") for kv in os.environ.get("CRT_FUZZ_ENV", "").split())
+    r = _renderer(crt, sc, cam, 77 + case, **fuzz_env)
     fb0, st0 = r.render(crt.CRT_WORLD_BVH, spp, s0, depth)
     r.set_count_stats(True)
     fb, st = r.render(crt.CRT_WORLD_BVH, spp, s0, depth)
