@@ -277,21 +277,22 @@ __device__ __forceinline__ void successor(uint32_t& k, uint32_t& pending, bool h
 
 // The same successor from the interval ends of the two children (child hit <=> !(hi <= lo)), hand-scheduled: the
 // compiler's form spends 13 vector instructions on it (two compares, two 0/1 materialisations, two shift-ors, ctz,
-// two shifts, two xors, two selects); this one 9 -- the descent is k + k + carry (v_addc_co_u32 with the lane masks
+// two shifts, two xors, two selects) and 3 scalar ones; this one 9 and 5 -- the descent is k + k + carry (v_addc_co_u32 with the lane masks
 // "left missed" / "both hit" as carry-in) and the select is done by the EXEC mask, which is restored before the block
 // ends.  k and pending are updated in place.  Identical results to successor() for every input (tests).
 __device__ __forceinline__ void successor_lohi(uint32_t& k, uint32_t& pending, float loL, float hiL, float loR, float hiR) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CRT_SUCCESSOR_PLAIN)
     uint32_t t0, t1;
     unsigned long long mL, mR, m_any, saved;
+    // mL / mR: lane masks "left child MISSED" / "right child missed" (hi <= lo; false for NaN, like the C expression);
+    // inactive lanes read 0 there, so `any` and `both` carry ones for them -- harmless, every use is under EXEC
     asm("v_ffbl_b32 %[t0], %[p]\n\t"
-        "v_cmp_nle_f32 %[mL], %[hiL], %[loL]\n\t"
-        "v_cmp_nle_f32 %[mR], %[hiR], %[loR]\n\t"
+        "v_cmp_le_f32 %[mL], %[hiL], %[loL]\n\t"
+        "v_cmp_le_f32 %[mR], %[hiR], %[loR]\n\t"
         "v_lshrrev_b32 %[t1], %[t0], %[k]\n\t"
         "v_lshrrev_b32 %[t0], %[t0], %[p]\n\t"
-        "s_or_b64 %[any], %[mL], %[mR]\n\t"
-        "s_and_b64 %[mR], %[mL], %[mR]\n\t"
-        "s_not_b64 %[mL], %[mL]\n\t"
+        "s_nand_b64 %[any], %[mL], %[mR]\n\t"           // any child hit
+        "s_nor_b64 %[mR], %[mL], %[mR]\n\t"             // both hit
         "s_and_saveexec_b64 %[sv], %[any]\n\t"          // lanes that descend
         "v_addc_co_u32 %[k], vcc, %[k], %[k], %[mL]\n\t"  // 2k + (left missed)
         "v_addc_co_u32 %[p], vcc, %[p], %[p], %[mR]\n\t"  // 2 pending + (both hit)

@@ -34,4 +34,10 @@ if [ "$with_c4" = "c4" ]; then
     timeout -s KILL 180 rocprofv3 --pmc $ctrs --output-format csv -d $out/${tag}_pmc_c4_$name -o p -- python3 $R/tools/tune.py $C4 "CRT_ARITH=exact" > $out/${tag}_pmc_c4_$name.log 2>&1 || { echo "pmc pass c4 $name failed"; tail -3 $out/${tag}_pmc_c4_$name.log; exit 1; }
   done
 fi
+# the walker/owner instance (SCHED=3): kernel time, lane utilisation and the LDS / wait counters of one C2 launch
+for grp in "a:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS" \
+           "f:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES"; do
+  name=${grp%%:*}; ctrs=${grp#*:}
+  timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d $out/${tag}_pmc_sched3_$name -o p -- python3 $R/tools/tune.py --spp 500 --rounds 1 "CRT_SCHED=3 CRT_SHADE_NUM=6" > $out/${tag}_pmc_sched3_$name.log 2>&1 || { echo "pmc pass sched3 $name failed"; tail -3 $out/${tag}_pmc_sched3_$name.log; exit 1; }
+done
 echo "profiles done"
