@@ -537,7 +537,10 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
             roofline["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
             roofline["traffic_source"] = f"committed profile {pmc.get('file')} (build {pmc.get('build_id')}, commit {pmc.get('commit')})"
             if "valu" in pmc:  # PMC view of the same kernel: what the SIMDs actually issue
-                roofline["pmc"] = pmc["valu"]
+                roofline["pmc"] = dict(pmc["valu"])
+                for k in ("l1_accesses_per_clk_per_cu", "l1_hit", "l2_hit", "wave_cycles_waiting_on_memory", "fetch_bytes_raw"):
+                    if k in pmc:  # C4: the memory-side counters of the same launch (profiles/<round>_pmc_summary.txt)
+                        roofline["pmc"][k] = pmc[k]
         else:
             roofline["traffic_source"] = (f"null: profiles/pmc_traffic.json was taken at build {pmc.get('build_id')} / "
                                           f"{pmc.get('kernel')}, this run is build {build['build_id']} / {kernel}")
@@ -557,12 +560,15 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
         rec_gs = I * cst.rays / kavg / 1e9
         roofline.update({"bound": "l1-request-rate", "achieved": rec_gs, "peak": L1_RECORD_RATE_PEAK_GS, "unit": "Grecords/s",
                          "frac": rec_gs / L1_RECORD_RATE_PEAK_GS,
-                         "fp32_TFLOPs": achieved_tflops, "hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+                         "fp32_TFLOPs": achieved_tflops, "frac_of_fp32_vector_peak": achieved_tflops / VALU_FP32_PEAK_TFLOPS,
+                         "hbm_GBs_measured": hbm_gbs, "hbm_peak_GBs": HBM_PEAK_GBS,
+                         "frac_of_hbm_peak_measured": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
                          "note": "scene (67 MB child-pair records + 32 MB spheres) is read by random access and fits the "
-                                 "256 MB Infinity Cache: measured memory-side traffic (PMC) is <=6% of the algorithmic bytes "
-                                 "(64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
-                                 "instance is bound by the L1's record rate (PMC: 67% of wave cycles waiting, L1 hit "
-                                 "79%, L2 hit 90%, ~1.0 L1 access per clock per CU); achieved = I x rays / time (child-pair "
+                                 "256 MB Infinity Cache: measured memory-side traffic (PMC, hbm_GBs_measured: fabric requests of "
+                                 "the L2s, Infinity-Cache hits included, FETCH_SIZE doubled) is about a tenth of the algorithmic "
+                                 "bytes (64 I + 32 S per ray = scene_fetch_GBs, which therefore exceeds the HBM peak): the "
+                                 "instance is bound by the L1's access rate (PMC of this build, roofline.pmc: ~0.9 L1 accesses per "
+                                 "clock per CU, L1 hit 76%, L2 hit 89%, 64% of wave cycles in s_waitcnt); achieved = I x rays / time (child-pair "
                                  "records per second, the upper ten levels come from LDS), peak = what "
                                  "tools/ubench/gather_quad.hip reaches with dependent 64-byte record reads from an "
                                  "L1-resident table and nothing else to do (250-290 G records/s chip-wide)",
