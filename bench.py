@@ -63,7 +63,7 @@ def parse_args(argv=None):
                          "tests/test_gpu_round2.py::test_fast_arithmetic_within_stated_tolerance).  The other mode is measured "
                          "beside it, untimed by the step clock (HIP events)")
     ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
-                    help="double-buffered steps: two contexts, two sums buffers and two streams per rank, so that the reduce + "
+                    help="pipelined steps: three contexts / sums buffers / stream pairs per rank, so that the reduce + "
                          "resolve of image k run behind the trace of image k+1 and the next launch's workgroups start in the "
                          "drain tail of the previous one (DESIGN.md 5).  auto = on for N > 1 (and the one-GPU rehearsals of "
                          "the N-rank path), off for N = 1: the driver's single-GPU line renders its steps strictly one after "
@@ -231,11 +231,11 @@ class GpuRank:
     def resolve(self, spp):
         self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.stream)
 
-    def make_slots(self):
-        """Two (context, sums, frame, stream) sets for double-buffered steps: launches that overlap on the GPU need a
-        context each (include/crt_hip.h), and each set works on a stream of its own."""
+    def make_slots(self, count=3):
+        """`count` (context, sums, frame, trace stream, combine stream) sets for pipelined steps: launches that overlap
+        on the GPU need a context each (include/crt_hip.h), and each set works on streams of its own."""
         torch, crt = self.torch, self.crt
-        for i in range(2):
+        for i in range(count):
             slot = GpuSlot()
             if i == 0:
                 slot.r, slot.sums, slot.frame = self.r, self.sums, self.frame
@@ -247,8 +247,10 @@ class GpuRank:
                 slot.r.set_camera(self.cam)
                 slot.sums = torch.zeros_like(self.sums)
                 slot.frame = torch.empty_like(self.frame)
-            slot.tstream = torch.cuda.Stream(device=self.dev)
+            slot.tstream = torch.cuda.Stream(device=self.dev)   # zeroing + trace
+            slot.cstream = torch.cuda.Stream(device=self.dev)   # reduce + resolve
             slot.stream = slot.tstream.cuda_stream
+            slot.traced, slot.free = torch.cuda.Event(), None
             slot.world, slot.depth = self.world, self.depth
             self.slots.append(slot)
         torch.cuda.synchronize()
@@ -268,8 +270,8 @@ class GpuSlot:
         self.r.render_accumulate(self.world, first, count, self.depth, self.sums.data_ptr(), self.stream,
                                  tile_stride=tile_stride, tile_offset=tile_offset)
 
-    def resolve(self, spp):
-        self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.stream)
+    def resolve(self, spp):  # on the slot's combine stream
+        self.r.resolve(self.sums.data_ptr(), spp, self.frame.data_ptr(), self.cstream.cuda_stream)
 
 
 class RehearsalRank:
@@ -297,13 +299,15 @@ class RehearsalRank:
     def resolve(self, spp):
         self.frame.copy_((self.sums.to(self.torch.float64) * (2.0 ** -40 / spp)).to(self.torch.float32))
 
-    def make_slots(self):
-        """CPU stand-in of GpuRank.make_slots: two sets of buffers, no streams."""
+    def make_slots(self, count=3):
+        """CPU stand-in of GpuRank.make_slots: `count` sets of buffers, no streams."""
         import copy
         self.tstream = None
-        other = copy.copy(self)
-        other.sums, other.frame = self.torch.zeros_like(self.sums), self.torch.empty_like(self.frame)
-        self.slots = [self, other]
+        self.slots = [self]
+        for _ in range(count - 1):
+            other = copy.copy(self)
+            other.sums, other.frame = self.torch.zeros_like(self.sums), self.torch.empty_like(self.frame)
+            self.slots.append(other)
         return self.slots
 
     def sync(self):
@@ -322,7 +326,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from cuda_ray_tracer_amd.multi_gpu import render_split, share_of_rank
+    from cuda_ray_tracer_amd.multi_gpu import reduce_sums, render_split, share_of_rank
 
     scene_kw, cam_kw = dict(half=11, ground_radius=1000.0), {}
     if args.config == "c4":  # the same generator on a 1000x1000 grid, camera pulled back 40x
@@ -373,27 +377,43 @@ def main():
         if rank == 0:
             g.resolve(args.spp)
 
-    # Double-buffered steps (N > 1): image k on slot k % 2 -- its own context, sums, frame and stream.  The zeroing, the
-    # trace, the reduce (torch orders the collective behind the CURRENT stream and the current stream behind the
-    # collective) and the resolve of image k are ordered on slot k % 2's stream; image k+1 runs on the other stream, so
-    # its trace fills the chip while image k drains, reduces and resolves.  A slot is reused two images later, behind
-    # its own previous resolve.  The frames are the un-pipelined frames bit for bit (integer sums).
+    # Pipelined steps (N > 1): image k on slot k mod 3 -- a context, sums, frame, trace stream and combine stream of its
+    # own.  Trace stream: zero the sums, trace this rank's share.  Combine stream, behind an event of the trace: the
+    # reduce (torch orders the collective behind the CURRENT stream and the current stream behind the collective) and,
+    # on rank 0, the resolve.  Image k+1 traces on ANOTHER slot's stream, so its workgroups start in the drain tail of
+    # image k while image k is reduced and resolved; with three slots the trace of image k+2 waits for nothing of
+    # image k either (with two it would queue behind k's resolve, which needs room on a chip that trace k+1 fills).
+    # A slot is reused three images later, behind its own previous combine.  Collectives are issued in step order on
+    # every rank.  The frames are the un-pipelined frames bit for bit (integer sums).
     pipelined = args.pipeline == "on" or (args.pipeline == "auto" and use_dist)
     if passes > 1:
         pipelined = False
-    slots = g.make_slots() if pipelined else []
+    slots = g.make_slots(3) if pipelined else []
     step_hashes = []
 
     def step_pipelined(k):
-        sl = slots[k % 2]
-        ctx = torch.cuda.stream(sl.tstream) if getattr(sl, "tstream", None) is not None else contextlib.nullcontext()
-        with ctx:
-            render_split(sl.trace, sl.sums, args.spp, world_size, rank, always_reduce=use_dist, split=args.split,
-                         host_staged=args.share_gpu)
+        sl = slots[k % len(slots)]
+        streams = getattr(sl, "tstream", None) is not None
+        with (torch.cuda.stream(sl.tstream) if streams else contextlib.nullcontext()):
+            if streams and sl.free is not None:
+                sl.tstream.wait_event(sl.free)  # this slot's previous reduce + resolve have read its sums
+            sl.sums.zero_()
+            if has_work:
+                sl.trace(share["first"], share["nsamples"], share["tile_stride"], share["tile_offset"])
+            if streams:
+                sl.traced.record(sl.tstream)
+        with (torch.cuda.stream(sl.cstream) if streams else contextlib.nullcontext()):
+            if streams:
+                sl.cstream.wait_event(sl.traced)
+            if use_dist:
+                reduce_sums(sl.sums, args.share_gpu)
             if rank == 0:
                 sl.resolve(args.spp)
                 if args.verify_steps:
                     step_hashes.append(hashlib.sha256(sl.frame.cpu().numpy().tobytes()).hexdigest())
+            if streams:
+                sl.free = torch.cuda.Event()
+                sl.free.record(sl.cstream)
 
     def sync():
         if use_dist:
@@ -425,7 +445,7 @@ def main():
         # stream around every launch (it keeps the last 64)
         if has_work and args.steps > 0 and pipelined:  # the timed launches are spread over the two contexts
             for i, sl in enumerate(slots):
-                mine = len([k for k in range(args.warmup, args.warmup + args.steps) if k % 2 == i])
+                mine = len([k for k in range(args.warmup, args.warmup + args.steps) if k % len(slots) == i])
                 if mine:
                     kernel_s += sl.r.kernel_times(min(mine, 64))
         elif has_work and args.steps > 0:
@@ -506,11 +526,17 @@ def gpu_report(args, g, out, share, kernel_s, world_size, np):
     bytes_per_ray = 64.0 * I + 32.0 * S
     passes = args.passes
     kavg = float(np.mean(kernel_s)) * passes  # kernel time of one image's launches on this rank
+    overlapped = bool(out.get("pipelined"))
+    if overlapped:
+        # pipelined steps: consecutive launches overlap on the chip (the next one starts in the drain of the previous
+        # one), so the events around ONE launch also cover its wait for room and part of its neighbours; the time the
+        # chip spends per image is the step time
+        kavg = out["ms_per_step"] * 1e-3
     achieved_tflops = flops_per_ray * cst.rays / kavg / 1e12
     roofline = {
         "bound": "valu", "achieved": achieved_tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved_tflops / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-        "kernel": kernel, "kernel_ms": kavg * 1e3,
+        "kernel": kernel, "kernel_ms": kavg * 1e3, "kernel_ms_is_step_time": overlapped,
         "rays_per_launch": int(cst.rays), "pair_visits_per_ray": I, "sphere_tests_per_ray": S,
         "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
         "scene_fetch_GBs": bytes_per_ray * cst.rays / kavg / 1e9,
