@@ -445,7 +445,7 @@ static int launch_accumulate(crt_context* ctx, int32_t world, int32_t sample_off
         // persistent waves: as many workgroups as the chip holds at once (LDS- or wave-limited), each
         // wave pulling (tile, sample chunk) units; coarse units sized for about 16 per wave, 8..32 samples each
         lds += size_t(n_own) * 260 * 8;  // per path-owning wave: one tile of accumulators, its unit state, 32 block requests
-        if (split_waves) lds += size_t(n_own) * 16 * (2 * 32 + 1 + 16);  // + its request ring, control words and mailboxes (CRT_XCHG_FLOAT4_PER_OWNER)
+        if (split_waves) lds += size_t(n_own) * 16 * CRT_XCHG_FLOAT4_PER_OWNER;  // + its request ring, control words and mailboxes
         a.n_walkers = n_walk; a.refill_min = ctx->refill_min; a.owner_sleep = ctx->owner_sleep;
         a.walker_backoff = ctx->walker_backoff; a.walker_prio = ctx->walker_prio;
         a.walker_min_busy = ctx->walker_min_busy; a.walker_patience = ctx->walker_patience;

@@ -46,6 +46,11 @@
 #define CRT_TIMELINE_BASE (CRT_STATS_BASE + 4 * CRT_STAT_STRIPES)
 #define CRT_COUNTER_WORDS (CRT_TIMELINE_BASE + 3 * 8192)
 
+// SCHED=3 exchange area of one owner wave in LDS (crt_kernels.hip walker_loop): a request ring of CRT_RING_CAP entries of two
+// float4 (SoA), one float4 of control words {tail, head, done, -}, 64 mailbox words
+#define CRT_RING_CAP 32u
+#define CRT_XCHG_FLOAT4_PER_OWNER (2 * CRT_RING_CAP + 1 + 16)
+
 struct crt_dev_camera {
     float center[3], p00[3], du[3], dv[3], ddu[3], ddv[3];
     float defocus_angle;

@@ -616,9 +616,7 @@ struct walk_scene {
 //          leaf held for the sphere phase, bit 0 of pending = its sibling was hit too)
 // DS operations of one wave execute in issue order, so "entry, then tail" / "entry read, then head" need no more
 // than the compiler keeping that order (workgroup-scope fences).
-#define CRT_RING_CAP 32u
-#define CRT_MBOX_VALID 0x80000000u
-#define CRT_XCHG_FLOAT4_PER_OWNER (2 * CRT_RING_CAP + 1 + 16)  // ring halves, ctl, 64 mailbox words
+#define CRT_MBOX_VALID 0x80000000u  // (CRT_RING_CAP, CRT_XCHG_FLOAT4_PER_OWNER: crt_device.h, the launcher sizes the LDS with them)
 
 struct owner_link {
     uint32_t q0, q1;  // LDS byte offsets of the two ring halves of this owner wave
