@@ -15,7 +15,7 @@ run() {  # name, environment assignments, pytest -k expression
   case "$line" in *failed*|*error*) exit 1;; esac
 }
 : > $out
-run "scene/camera/depth fuzz, 4000 seeded cases (seeds 1000..4999), frame + ray count + traversal counters vs oracle" "CRT_FUZZ_CASES=4000" "fuzz_scene" || exit 1
+run "scene/camera/depth fuzz, 12000 seeded cases (seeds 1000..12999), frame + ray count + traversal counters vs oracle" "CRT_FUZZ_CASES=12000" "fuzz_scene" || exit 1
 run "the same, first 600 cases, walker/owner instance" "CRT_FUZZ_CASES=600 CRT_FUZZ_ENV=CRT_SCHED=3" "fuzz_scene" || exit 1
 run "the same, first 600 cases, scene read from HBM (no LDS image)" "CRT_FUZZ_CASES=600 CRT_FUZZ_ENV=CRT_LDS_LIMIT=0" "fuzz_scene" || exit 1
 run "GPU BVH builder vs host replay of the reference's recursion, 14 fixed + 200 random sizes in 1..20000, tie-heavy and random scenes" "CRT_BVH_FUZZ_SIZES=200" "bvh_builder or bvh_readback" || exit 1

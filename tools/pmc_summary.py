@@ -121,7 +121,7 @@ def main(tag):
     print("# derived:")
     for d, _ in rows:
         print(f"#   {d['mode']}: {d['kernel']}")
-        print(f"#     kernel time under the PMC profiler {d['ms']:.2f} ms, {d['rays']} rays per launch, shader clock {d.get('clock_GHz', float('nan')):.3f} GHz")
+        print(f"#     kernel time under the PMC profiler {d['ms']:.2f} ms, {d['rays']} rays per launch" + (f", shader clock {d['clock_GHz']:.3f} GHz" if "clock_GHz" in d else ""))
         print(f"#     VALU wave-instructions per ray {d['valu_per_ray']:.2f}" + (f", SALU {d['salu_per_ray']:.2f}" if "salu_per_ray" in d else "")
               + f"; lane utilisation of VALU instructions {f(d['lane_util'])} (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)); "
               f"VALU issue busy {f(d['valu_busy'])} (2 cycles per wave64 instruction)")
@@ -137,7 +137,7 @@ def main(tag):
         if "fetch_raw_B" in d:
             sec = d["ms"] * 1e-3
             print(f"#     memory side per launch: FETCH_SIZE {d['fetch_raw_B'] / 1e6:.2f} MB raw (x2 gfx950 correction = {2 * d['fetch_raw_B'] / 1e6:.2f} MB), "
-                  f"WRITE_SIZE {d['write_B'] / 1e6:.2f} MB = {d['fetch_raw_B'] / sec / 1e9:.1f}-{2 * d['fetch_raw_B'] / sec / 1e9:.1f} GB/s read, {d['write_B'] / sec / 1e9:.1f} GB/s written")
+                  f"WRITE_SIZE {d['write_B'] / 1e6:.2f} MB = {d['fetch_raw_B'] / sec / 1e9:.3g}-{2 * d['fetch_raw_B'] / sec / 1e9:.3g} GB/s read, {d['write_B'] / sec / 1e9:.1f} GB/s written")
         if "l1_hit" in d:
             print(f"#     L1 (TCP): {d['l1_accesses_per_clk_per_cu']:.2f} cache accesses per clock per CU, hit rate {f(d['l1_hit'])}; L2 (TCC) hit rate "
                   f"{f(d.get('l2_hit'))}, misses x 64 B = {d.get('l2_miss_B_at_64', 0) / 1e9:.0f} GB per launch")
