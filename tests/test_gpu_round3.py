@@ -10,7 +10,9 @@ statistics), through the C ABI (crt_trace_samples: primary ray, radiance and seg
   * lambertian scatter is cosine-weighted (material.h:28, vec3.h:145-152): hit fraction of an absorber above the
     surface against the point-to-sphere form factor cos(beta) (R/D)^2, overhead and at a slant;
   * get_ray (render_with_cuda.h:11-26): lens samples uniform on the defocus disk, pixel offsets uniform in the pixel,
-    time uniform on [0,1) (chi-square).
+    time uniform on [0,1) (chi-square); and the primary ray itself, bit for bit, from the Philox stream and the
+    reference's fp32 expressions in numpy float32;
+  * the first scatter of a fuzzy metal and of a lambertian ball replayed from the stream (material.h:26-38,48-55).
 """
 import os
 
@@ -459,3 +461,142 @@ def test_lens_pixel_and_time_samples_are_uniform(crt):
     # lens sample, pixel offset and time come from different words / blocks of the stream: no correlation
     for a, b in ((x, y), (x, tm), (uv[0] - px, tm), (r2, uv[1] - py)):
         assert abs(np.corrcoef(a, b)[0, 1]) < 5 / np.sqrt(n)
+
+
+# ---- (v) the draw plan replayed: primary rays bit for bit, and the first scatter of metal / lambertian -------------
+
+def _stream(seed, W, px, py, smp):
+    """block(event) of the Philox stream of the paths (px, py, smp): counter (event, sample, pixel, 0), key = seed."""
+    pixel, sample = (np.asarray(py) * W + np.asarray(px)).astype(np.uint64), np.asarray(smp).astype(np.uint64)
+    zero = np.zeros(len(pixel), np.uint64)
+    return lambda event: philox4x32_10(np.asarray(event, np.uint64), sample, pixel, zero, seed & 0xffffffff, seed >> 32)
+
+
+def _rf11(u):  # rtweekend.h:25-28 in fp32: -1 + 2 * (1 - u)
+    return np.float32(-1.0) + np.float32(2.0) * (np.float32(1.0) - u)
+
+
+def _disk_sample(block, n):
+    """vec3.h:154-160 from event 1 on, two attempts per block: the accepted (x, y) in fp32 and the next event index."""
+    one = np.float32(1.0)
+    event, open_ = np.ones(n, np.uint64), np.ones(n, bool)
+    dx, dy = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for _ in range(16):
+        x0, y0, x1, y1 = (_rf11(u01(v)) for v in block(event))
+        ok0, ok1 = (x0 * x0 + y0 * y0) < one, (x1 * x1 + y1 * y1) < one
+        t0, t1 = open_ & ok0, open_ & ~ok0 & ok1
+        dx, dy = np.where(t0, x0, np.where(t1, x1, dx)), np.where(t0, y0, np.where(t1, y1, dy))
+        event = np.where(open_, event + np.uint64(1), event)
+        open_ = open_ & ~(ok0 | ok1)
+    assert not open_.any()
+    return dx, dy, event
+
+
+def _unit_vector(block, event, todo):
+    """vec3.h:145-152 from `event` on, one block per attempt: the accepted vector (float64 unit) and the blocks drawn."""
+    n = len(event)
+    used, open_ = np.zeros(n, np.uint64), todo.copy()
+    v = np.zeros((n, 3))
+    for _ in range(64):
+        if not open_.any():
+            break
+        x, y, z = (_rf11(u01(w)) for w in block(event + used)[:3])
+        l2 = x * x + y * y + z * z
+        ok = (np.float32(0.0) < l2) & (l2 <= np.float32(1.0))
+        take = open_ & ok
+        v[take] = (np.stack([x, y, z], axis=1)[take].astype(np.float64)) / np.sqrt(l2[take].astype(np.float64))[:, None]
+        used = np.where(open_, used + np.uint64(1), used)
+        open_ = open_ & ~ok
+    assert not open_.any()
+    return v, used
+
+
+@pytest.mark.gpu
+def test_primary_ray_replayed_from_the_philox_stream(crt):
+    """get_ray (render_with_cuda.h:6-29) from the stream alone: the camera block gives the pixel offsets and the time
+    (DESIGN.md D16), the disk blocks the lens sample; origin and direction are then the reference's fp32 expressions,
+    one rounding per operation, in numpy float32.  200 000 primary rays at C2's camera (defocus 0.6): bit for bit."""
+    seed, W, spp = 4242, 1200, 500
+    cam = crt.camera(W, spp)
+    r = _renderer(crt, crt.scene_random(18, 3), cam, seed)
+    rng = np.random.default_rng(21)
+    n = 200000
+    px, py, smp = rng.integers(0, W, n), rng.integers(0, cam.image_height, n), rng.integers(0, spp, n)
+    ray7, _, _ = r.trace_samples(crt.CRT_WORLD_BVH, px, py, smp, 1)
+    r.close()
+    block = _stream(seed, W, px, py, smp)
+    b0 = block(np.zeros(n, np.uint64))
+    half, one = np.float32(0.5), np.float32(1.0)
+    x_off, y_off, tm = u01(b0[0]) - half, u01(b0[1]) - half, one - u01(b0[2])
+    dx, dy, _ = _disk_sample(block, n)
+    f = lambda v: np.array(v[:], np.float32)
+    c, p00, du, dv, ddu, ddv = (f(v) for v in (cam.center, cam.pixel00_loc, cam.pixel_delta_u, cam.pixel_delta_v,
+                                                cam.defocus_disk_u, cam.defocus_disk_v))
+    sx, sy = px.astype(np.float32) + x_off, py.astype(np.float32) + y_off
+    sample_pt = (p00[None, :] + sx[:, None] * du[None, :]) + sy[:, None] * dv[None, :]
+    origin = (c[None, :] + dx[:, None] * ddu[None, :]) + dy[:, None] * ddv[None, :]
+    want = np.concatenate([origin, sample_pt - origin, tm[:, None]], axis=1).astype(np.float32)
+    assert _bits_equal(ray7, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", ["bvh", "list"])
+@pytest.mark.parametrize("material", ["metal_fuzz", "lambertian"])
+def test_first_scatter_replayed_from_the_philox_stream(crt, world, material):
+    """material.h:26-38 / 48-55 with the stream's own unit vector: a ball S (metal, fuzz 0.4 -- or lambertian) and an
+    absorber T.  For a primary ray that hits S first, the float64 replay draws random_unit_vector from the blocks that
+    follow the disk blocks (one block per attempt), forms unit(reflect(d, n)) + 0.4 u (metal: absorbed -- black after
+    ONE segment -- exactly when that direction points into the surface) or n + u (lambertian), and follows it: onto T
+    (black after two segments) or to the sky (lit, two segments).  Every path's (black, segments) must come out as
+    predicted; decisions within rounding of their threshold are left out."""
+    seed, W, spp, fuzz = 99, 320, 64, 0.4
+    s_c, s_r = np.array([0.0, 0.0, 0.0]), 1.0
+    t_c, t_r = np.array([1.9, 1.7, 0.4]), 0.9
+    mtype = crt.CRT_METAL if material == "metal_fuzz" else crt.CRT_LAMBERTIAN
+    sc = crt.Scene([s_c, t_c], np.zeros((2, 3)), [s_r, t_r], [0, 1], [mtype, crt.CRT_MATERIAL_BASE],
+                   [[0.8, 0.7, 0.6], [0, 0, 0]], [fuzz, 0.0])
+    cam = crt.camera(W, spp, vfov=16.0, lookfrom=(6.5, 1.2, 0.8), lookat=(0, 0, 0), defocus_angle=0.0, focus_dist=6.5)
+    r = _renderer(crt, sc, cam, seed, bvh=world == "bvh")
+    rng = np.random.default_rng(22)
+    n = 120000
+    px, py, smp = rng.integers(0, W, n), rng.integers(0, cam.image_height, n), rng.integers(0, spp, n)
+    ray7, rgb, seg = r.trace_samples(crt.CRT_WORLD_BVH if world == "bvh" else crt.CRT_WORLD_LIST, px, py, smp, 50)
+    r.close()
+    block = _stream(seed, W, px, py, smp)
+    _, _, event = _disk_sample(block, n)
+    o, d = ray7[:, 0:3].astype(np.float64), ray7[:, 3:6].astype(np.float64)
+    t_s, _, m_s = _roots(o, d, s_c, s_r)
+    t_t, _, m_t = _roots(o, d, t_c, t_r)
+    first_s = ~np.isnan(t_s) & (np.isnan(t_t) | (t_s < t_t)) & (np.abs(m_s) > 1e-4) & (np.isnan(t_t) | (np.abs(m_t) > 1e-4))
+    p = o + np.nan_to_num(t_s)[:, None] * d
+    nrm = (p - s_c) / s_r
+    u, _ = _unit_vector(block, event, first_s)
+    if material == "metal_fuzz":
+        refl = d - 2 * (d * nrm).sum(1)[:, None] * nrm
+        direction = _unit(np.where(first_s[:, None], refl, 1.0)) + fuzz * u
+    else:
+        direction = nrm + u
+    facing = (direction * nrm).sum(1)
+    absorbed = (facing <= 0) if material == "metal_fuzz" else np.zeros(n, bool)
+    t2, _, m2 = _roots(p, _unit(np.where(first_s[:, None], direction, 1.0)), t_c, t_r)
+    on_target = ~np.isnan(t2) & (np.nan_to_num(t2) > 1e-3)
+    # (a direction within a few degrees of the tangent plane can meet S again beyond t = 0.001 within fp32 rounding --
+    # the reference's own acne, sphere.h:59-64 -- and a metal direction within rounding of the plane can flip the
+    # absorption test: both left out)
+    grazing = np.abs(facing) < 0.05 * np.linalg.norm(direction, axis=1)
+    sure = first_s & ~grazing & (np.abs(m2) > 1e-4) & (np.linalg.norm(direction, axis=1) > 1e-3)
+    pred_black = absorbed | on_target
+    pred_seg = np.where(absorbed, 1, 2)
+    black = (rgb == 0).all(axis=1)
+    assert sure.sum() > 40000 and (sure & on_target & ~absorbed).sum() > 1500
+    if material == "metal_fuzz":
+        assert (sure & absorbed).sum() > 300
+    assert np.array_equal(black[sure], pred_black[sure])
+    assert np.array_equal(seg[sure], pred_seg[sure])
+    lit = sure & ~pred_black                      # one bounce: attenuation = albedo, sky of the PRIMARY ray (D2)
+    dd = ray7[:, 3:6]
+    len2 = dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2]
+    a = np.float32(0.5) * ((np.float32(1.0) / np.sqrt(len2)) * dd[:, 1] + np.float32(1.0))
+    sky = np.stack([(np.float32(1.0) - a) * np.float32(1.0) + a * np.float32(c) for c in (0.5, 0.7, 1.0)], axis=1)
+    albedo = np.array([0.8, 0.7, 0.6], np.float32)
+    assert _bits_equal(rgb[lit], (albedo[None, :] * sky[lit]).astype(np.float32))
