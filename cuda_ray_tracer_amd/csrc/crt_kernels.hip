@@ -83,14 +83,23 @@ __device__ __forceinline__ v3 unit(v3 a) { return rsqrt_(len2(a)) * a; }  // vec
 __device__ __forceinline__ float lensq3(float x, float y, float z) { return len2(mk(x, y, z)); }
 
 // ---- Philox4x32-10, counter = (event, sample, pixel, 0), key = seed -------------------------
+// a ^ b ^ c as ONE instruction: gfx950's v_bitop3_b32 with the truth table of the three-input xor (the compiler
+// emits two v_xor_b32 for the plain expression: 20 of the ~60 VALU instructions of a block)
+__device__ __forceinline__ uint32_t xor3(uint32_t x, uint32_t y, uint32_t z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)x, (int)y, (int)z, 0x96);
+#else
+    return x ^ y ^ z;  // host pass of the single-source compile: never runs
+#endif
+}
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0;
         const unsigned long long m1 = (unsigned long long)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(m1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(m0 >> 32), c3, k1);
         c0 = n0; c1 = (uint32_t)m1; c2 = n2; c3 = (uint32_t)m0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -99,7 +108,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 }
 
 // (0,1], rocRAND's mapping; v * 2^-32 is exact, so the sum is one rounding
-__device__ __forceinline__ float u01(uint32_t v) { return 2.3283064e-10f + ((float)v * 2.3283064e-10f); }
+// (as one fma: the product by a power of two is exact, so the fma rounds what the separate add rounds)
+__device__ __forceinline__ float u01(uint32_t v) { return __builtin_fmaf((float)v, 2.3283064e-10f, 2.3283064e-10f); }
 
 struct stream {
     uint32_t k0, k1, pixel, sample, event;
@@ -111,7 +121,8 @@ struct stream {
 };
 
 // random_float(state, -1, 1) = min + (max - min) * (1 - u), rtweekend.h:25-28
-__device__ __forceinline__ float rf11(float u) { return -1.0f + 2.0f * (1.0f - u); }
+// (2 * x is exact, so fma(2, x, -1) is the separately rounded sum bit for bit)
+__device__ __forceinline__ float rf11(float u) { return __builtin_fmaf(2.0f, 1.0f - u, -1.0f); }
 
 // vec3.h:145-152 -- one Philox block per attempt
 __device__ __forceinline__ v3 random_unit_vector(stream& rs) {
@@ -283,24 +294,27 @@ __device__ __forceinline__ void successor(uint32_t& k, uint32_t& pending, bool h
 __device__ __forceinline__ void successor_lohi(uint32_t& k, uint32_t& pending, float loL, float hiL, float loR, float hiR) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CRT_SUCCESSOR_PLAIN)
     uint32_t t0, t1;
-    unsigned long long mL, mR, m_any, saved;
-    // mL / mR: lane masks "left child MISSED" / "right child missed" (hi <= lo; false for NaN, like the C expression);
+    unsigned long long mL, m_any, saved;
+    // mL / VCC: lane masks "left child MISSED" / "right child missed" (hi <= lo; false for NaN, like the C expression);
     // inactive lanes read 0 there, so `any` and `both` carry ones for them -- harmless, every use is under EXEC
     asm("v_ffbl_b32 %[t0], %[p]\n\t"
         "v_cmp_le_f32 %[mL], %[hiL], %[loL]\n\t"
-        "v_cmp_le_f32 %[mR], %[hiR], %[loR]\n\t"
+        "v_cmp_le_f32 vcc, %[hiR], %[loR]\n\t"
         "v_lshrrev_b32 %[t1], %[t0], %[k]\n\t"
         "v_lshrrev_b32 %[t0], %[t0], %[p]\n\t"
-        "s_nand_b64 %[any], %[mL], %[mR]\n\t"           // any child hit
-        "s_nor_b64 %[mR], %[mL], %[mR]\n\t"             // both hit
+        "s_nand_b64 %[any], %[mL], vcc\n\t"            // any child hit
+        "s_nor_b64 vcc, %[mL], vcc\n\t"                // both hit
         "s_and_saveexec_b64 %[sv], %[any]\n\t"          // lanes that descend
-        "v_addc_co_u32 %[k], vcc, %[k], %[k], %[mL]\n\t"  // 2k + (left missed)
-        "v_addc_co_u32 %[p], vcc, %[p], %[p], %[mR]\n\t"  // 2 pending + (both hit)
+        // (the carry comes in through VCC: with any other scalar pair as carry-in a v_addc_co_u32 occupies the SIMD
+        // twice as long -- tools/ubench/valu_pair.hip -- which is worth the one s_mov_b64)
+        "v_addc_co_u32 %[p], vcc, %[p], %[p], vcc\n\t"  // 2 pending + (both hit)
+        "s_mov_b64 vcc, %[mL]\n\t"
+        "v_addc_co_u32 %[k], vcc, %[k], %[k], vcc\n\t"  // 2k + (left missed)
         "s_andn2_b64 exec, %[sv], %[any]\n\t"           // lanes that pop
         "v_xor_b32 %[k], 1, %[t1]\n\t"
         "v_xor_b32 %[p], 1, %[t0]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [k] "+v"(k), [p] "+v"(pending), [t0] "=&v"(t0), [t1] "=&v"(t1), [mL] "=&s"(mL), [mR] "=&s"(mR),
+        : [k] "+v"(k), [p] "+v"(pending), [t0] "=&v"(t0), [t1] "=&v"(t1), [mL] "=&s"(mL),
           [any] "=&s"(m_any), [sv] "=&s"(saved)
         : [loL] "v"(loL), [hiL] "v"(hiL), [loR] "v"(loR), [hiR] "v"(hiR)
         : "vcc");
