@@ -18,6 +18,8 @@
 
 #include <cmath>
 
+#include <cstddef>
+
 #include "crt_device.h"
 #include "crt_launch.h"
 
@@ -94,6 +96,13 @@ __device__ __forceinline__ uint32_t xor3(uint32_t x, uint32_t y, uint32_t z) {
 }
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The key is uniform, so the round keys are scalar adds.  Opaque here, they are formed where the block is drawn (18
+    // s_add_u32); visible, the compiler forms all twenty once per kernel and keeps them in scalar registers across the
+    // whole state machine, runs out of those and parks values in the lanes of a vector register -- v_readlane_b32 in
+    // the block loop, each as dear as two fp32 instructions (tools/ubench/valu_pair.hip).
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0;
@@ -492,6 +501,29 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 __device__ __forceinline__ unsigned long long to_fixed(float r) {
     return (unsigned long long)(long long)(fminf(r, 4096.0f) * 1099511627776.0f);  // 2^40; NaN -> 4096
 }
+
+// The camera vectors of the kernel argument, read by scalar loads AT THE POINT OF USE (a new path's primary ray).  Read
+// through `a.cam`, the compiler loads the 18 floats once per kernel, holds them in scalar registers across the whole
+// state machine, runs out of those and parks them in the lanes of a vector register: 18 v_readlane_b32 per shade
+// phase, each as dear as two fp32 instructions (tools/ubench/valu_pair.hip), and one VGPR less for everything else.
+struct cam_ref {
+    enum { center = 0, p00 = 3, du = 6, dv = 9, ddu = 12, ddv = 15 };  // float offsets in crt_dev_camera
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const float kfloat;
+    kfloat* f;
+    __device__ __forceinline__ explicit cam_ref(const crt_render_args&) {
+        // the kernel's only argument starts the kernel-argument segment, the camera starts the argument
+        static_assert(offsetof(crt_render_args, cam) == 0 && offsetof(crt_dev_camera, center) == 0 &&
+                      offsetof(crt_dev_camera, ddv) == 15 * sizeof(float), "camera layout");
+        f = (kfloat*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(f));  // not a known invariant load any more: stays where it is written
+    }
+#else
+    const float* f;
+    __device__ __forceinline__ explicit cam_ref(const crt_render_args& a) : f(a.cam.center) {}  // host pass of the single-source compile: never runs
+#endif
+    __device__ __forceinline__ v3 v(int at) const { return mk(f[at], f[at + 1], f[at + 2]); }
+};
 
 // Wave-scheduled BVH path tracer.  Every lane is a small state machine:
 //   RUN    walking internal nodes (one child-pair record per step),
@@ -1282,10 +1314,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         fresh = true;                          // takes its next item in the next shade phase
                     }
                 } else if (!fresh && !finished) {  // new path: render_with_cuda.h:14-28
-                    const v3 pixel_sample = (ld3(a.cam.p00) + (((float)px + u0) * ld3(a.cam.du))) +
-                                            (((float)py + u1) * ld3(a.cam.dv));
-                    const v3 p_in_disk = (ld3(a.cam.center) + dx * ld3(a.cam.ddu)) + dy * ld3(a.cam.ddv);
-                    p.r.o = (a.cam.defocus_angle <= 0.0f) ? ld3(a.cam.center) : p_in_disk;
+                    const cam_ref cam(a);  // the camera's 18 floats by scalar loads, here
+                    const v3 pixel_sample = (cam.v(cam.p00) + (((float)px + u0) * cam.v(cam.du))) +
+                                            (((float)py + u1) * cam.v(cam.dv));
+                    const v3 p_in_disk = (cam.v(cam.center) + dx * cam.v(cam.ddu)) + dy * cam.v(cam.ddv);
+                    p.r.o = (a.cam.defocus_angle <= 0.0f) ? cam.v(cam.center) : p_in_disk;
                     p.r.d = pixel_sample - p.r.o;
                     p.r.tm = u2;
                     p.thr = mk(1.0f, 1.0f, 1.0f);
