@@ -118,6 +118,10 @@ def load(path=LIB_PATH):
     lib.crt_group_upload_bvh_nodes.argtypes = [vp, C.POINTER(BvhNode), C.c_int32]
     lib.crt_group_set_camera.argtypes = [vp, C.POINTER(Camera)]
     lib.crt_group_render.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.POINTER(RenderStats)]
+    try:  # absent from older builds (CRT_LIB_PATH A/Bs)
+        lib.crt_selftest_exact_math.argtypes = [vp, C.POINTER(C.c_uint64)]
+    except AttributeError:
+        pass
     lib.crt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]  # internal, not in the header
     try:  # absent from older builds (CRT_LIB_PATH A/Bs)
         lib.crt_debug_timeline.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]  # internal, not in the header

@@ -214,6 +214,23 @@ int crt_set_arith(crt_context* ctx, int32_t arith) {
     return CRT_OK;
 }
 
+int crt_selftest_exact_math(crt_context* ctx, uint64_t* out9) {
+    if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
+    if (!out9) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_selftest_exact_math: out9 is NULL");
+    CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    const unsigned long long init[9] = {0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull};
+    unsigned long long res[9];
+    CRT_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof init));
+    hipError_t e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = crt_launch_math_selftest(d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(res, d, sizeof res, hipMemcpyDeviceToHost);  // waits for the kernel
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, CRT_ERR_HIP, std::string("crt_selftest_exact_math: ") + hipGetErrorString(e));
+    for (int i = 0; i < 9; ++i) out9[i] = res[i];
+    return CRT_OK;
+}
+
 const char* crt_last_kernel_name(const crt_context* ctx) { return ctx ? ctx->last_kernel : "none"; }
 
 #ifndef CRT_BUILD_ID

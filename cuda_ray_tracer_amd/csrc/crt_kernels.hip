@@ -76,10 +76,87 @@ __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 #else
-__device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
-__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
-__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+// 1 / x as the reference's division rounds it.  For 2^-100 <= |x| <= 2^100 the hardware's 1-ulp reciprocal and one
+// Newton step in two fmas -- r0 + r0 (1 - x r0) -- give the correctly rounded quotient: 3 instructions where the
+// compiler's division sequence (two v_div_scale, v_rcp, five fmas, v_div_fmas, v_div_fixup: built for every exponent)
+// takes 11.  The general sequence runs only when some lane of the wave holds an x outside that range (0, inf, NaN,
+// denormals, the far ends).  PROVEN for every one of the 2^32 arguments by comparison with the compiler's division on
+// the device: crt_selftest_reciprocal, tests/test_gpu_round3.py.
+__device__ __forceinline__ bool rcp_plain(float x) {  // false for NaN
+    return __builtin_amdgcn_fmed3f(__builtin_fabsf(x), 0x1p-100f, 0x1p+100f) == __builtin_fabsf(x);
+}
+__device__ __forceinline__ float rcp_newton(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float rcp_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = rcp_newton(x);
+    const bool plain = rcp_plain(x);
+    if (__builtin_expect(__ballot(!plain) != 0, 0)) {
+        if (!plain) r = 1.0f / x;
+    }
+    return r;
+#else
+    return 1.0f / x;  // host pass of the single-source compile: never runs
 #endif
+}
+// sqrtf(x) as the reference's rounds it.  For 2^-96 <= x < inf this is the compiler's own correctly rounded sequence
+// (v_sqrt_f32, then the neighbours one ulp down and up tried by their fma residuals) WITHOUT its scaling of small
+// arguments and its fix-up of 0 / inf: 9 instructions instead of 16; anything else -- 0, denormals, inf, negative, NaN --
+// takes the general sequence, when some lane of the wave holds one.  PROVEN for all 2^32 arguments like rcp_().
+__device__ __forceinline__ bool sqrt_plain(float x) {  // false for NaN and for x < 0
+    return __builtin_amdgcn_fmed3f(x, 0x1p-96f, 0x1.fffffep+127f) == x;
+}
+__device__ __forceinline__ float sqrt_short(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+    float r = (r_down <= 0.0f) ? down : s;
+    r = (r_up > 0.0f) ? up : r;
+    return r;
+}
+__device__ __forceinline__ float sqrt_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = sqrt_short(x);
+    const bool plain = sqrt_plain(x);
+    if (__builtin_expect(__ballot(!plain) != 0, 0)) {
+        if (!plain) r = sqrtf(x);
+    }
+    return r;
+#else
+    return sqrtf(x);  // host pass of the single-source compile: never runs
+#endif
+}
+// 1 / sqrtf(x): a plain x has its root in [2^-48, 2^64], which is plain for the reciprocal -- one range test for both
+__device__ __forceinline__ float rsqrt_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = rcp_newton(sqrt_short(x));
+    const bool plain = sqrt_plain(x);
+    if (__builtin_expect(__ballot(!plain) != 0, 0)) {
+        if (!plain) r = 1.0f / sqrtf(x);
+    }
+    return r;
+#else
+    return 1.0f / sqrtf(x);  // host pass of the single-source compile: never runs
+#endif
+}
+#endif
+// the three reciprocals of a direction, with one range test for the three
+__device__ __forceinline__ v3 rcp3(v3 d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !CRT_FAST
+    v3 r = mk(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const bool plain = (fminf(fminf(ax, ay), az) >= 0x1p-100f) & (fmaxf(fmaxf(ax, ay), az) <= 0x1p+100f);
+    const bool ordered = (d.x == d.x) & (d.y == d.y) & (d.z == d.z);  // min / max drop a NaN: test for it
+    if (__builtin_expect(__ballot(!(plain & ordered)) != 0, 0)) {
+        if (!(plain & ordered)) r = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    }
+    return r;
+#else
+    return mk(rcp_(d.x), rcp_(d.y), rcp_(d.z));
+#endif
+}
 __device__ __forceinline__ v3 unit(v3 a) { return rsqrt_(len2(a)) * a; }  // vec3.h:114-116,130-132: v / t == (1/t) * v
 // squared length of a rejection-sampling attempt (vec3.h:147-149,156-158: x*x + y*y + z*z, z = 0 for the disk)
 __device__ __forceinline__ float lensq3(float x, float y, float z) { return len2(mk(x, y, z)); }
@@ -1332,7 +1409,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                     if (NL == 1u) {
                         // the root is the only leaf (k >= NL: sphere phase next): no box is tested
                     } else {
-                        inv = mk(rcp_(p.r.d.x), rcp_(p.r.d.y), rcp_(p.r.d.z));  // aabb.h:48
+                        inv = rcp3(p.r.d);  // aabb.h:48
                         exact = !finite3(inv);
                         if (IN_LDS) {
                             offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
@@ -1616,6 +1693,34 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
     return hipErrorInvalidValue;
 }
 
+#if !CRT_FAST
+// Proof by exhaustion for rcp_(), sqrt_() and rsqrt_(): every one of the 2^32 arguments against the compiler's
+// correctly rounded division and square root.  Per function f = 0, 1, 2: out[3f] = arguments whose results differ (as
+// bit patterns; two NaNs count as equal), out[3f + 1] = the smallest such argument's bits (else ~0), out[3f + 2] =
+// arguments that took the short sequence.
+__global__ __launch_bounds__(256) void math_selftest_kernel(unsigned long long* out) {
+    const unsigned long long n_threads = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad[3] = {0, 0, 0}, plain[3] = {0, 0, 0}, first[3] = {~0ull, ~0ull, ~0ull};
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += n_threads) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float want[3] = {1.0f / x, sqrtf(x), 1.0f / sqrtf(x)};
+        const float got[3] = {rcp_(x), sqrt_(x), rsqrt_(x)};
+        const bool is_plain[3] = {rcp_plain(x), sqrt_plain(x), sqrt_plain(x)};
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const bool same = (__float_as_uint(want[f]) == __float_as_uint(got[f])) | ((want[f] != want[f]) & (got[f] != got[f]));
+            if (!same) { ++bad[f]; if (i < first[f]) first[f] = i; }
+            if (is_plain[f]) ++plain[f];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (bad[f]) { atomicAdd(&out[3 * f], bad[f]); atomicMin(&out[3 * f + 1], first[f]); }
+        atomicAdd(&out[3 * f + 2], plain[f]);
+    }
+}
+#endif
+
 }  // inline namespace arith_exact / arith_fast
 }  // namespace
 
@@ -1630,6 +1735,10 @@ hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp
 // dst[i] += src[0][i] + ... + src[n-1][i]: the frames of a group's other members (crt_group_render), integer sums
 hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& src, size_t count, hipStream_t stream) {
     hipLaunchKernelGGL(sum_frames_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, dst, src, count);
+    return hipGetLastError();
+}
+hipError_t crt_launch_math_selftest(unsigned long long* out9, hipStream_t stream) {
+    hipLaunchKernelGGL(math_selftest_kernel, dim3(256 * 16), dim3(256), 0, stream, out9);
     return hipGetLastError();
 }
 #define crt_launch_render_tu crt_launch_render

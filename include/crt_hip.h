@@ -233,6 +233,18 @@ int crt_set_arith(crt_context* ctx, int32_t arith);
 const char* crt_last_kernel_name(const crt_context* ctx);
 const char* crt_build_id(void);
 
+/* Self-test of the exact mode's reciprocal, square root and reciprocal square root.  The reference divides and calls
+ * sqrt (1 / direction component, aabb.h:48; v / t = (1/t) * v and unit_vector, vec3.h:114-132; 1 / radius and the
+ * discriminant's root, sphere.h:55-66; material.h:73,  vec3.h:141).  For arguments of ordinary size -- |x| in
+ * [2^-100, 2^100] for 1/x, x in [2^-96, inf) for the root -- the kernels use short sequences (v_rcp_f32 + one Newton
+ * step, 3 instructions for the general division's 11; v_sqrt_f32 + the two one-ulp neighbours tried by their
+ * residuals, 9 for 16) and the general ones for the rest.  This call proves on ctx's GPU that the results are the
+ * same: it evaluates both forms of all three functions for EVERY one of the 2^32 arguments.  out9 = for 1/x, sqrt(x),
+ * 1/sqrt(x) in turn: {number of arguments whose results differ as bit patterns (two NaNs count as equal) -- must be 0,
+ * the smallest such argument's bits (~0 if none), number of arguments on the short sequence}.
+ * No counterpart in the reference.  ~1 s. */
+int crt_selftest_exact_math(crt_context* ctx, uint64_t* out9);
+
 /* Debug/parity: primary ray (7 floats), radiance (3 floats) and number of closest-hit
  * queries of single (pixel, sample) paths, computed by the same device functions as the
  * render kernel.  px/py/sample are arrays of `count` entries; outputs are host buffers. */

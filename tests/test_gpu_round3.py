@@ -600,3 +600,20 @@ def test_first_scatter_replayed_from_the_philox_stream(crt, world, material):
     sky = np.stack([(np.float32(1.0) - a) * np.float32(1.0) + a * np.float32(c) for c in (0.5, 0.7, 1.0)], axis=1)
     albedo = np.array([0.8, 0.7, 0.6], np.float32)
     assert _bits_equal(rgb[lit], (albedo[None, :] * sky[lit]).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_short_reciprocal_and_root_are_the_general_ones_for_every_argument(crt):
+    """The exact kernels form 1/x (aabb.h:48, vec3.h:114-116, sphere.h:66) for |x| in [2^-100, 2^100] from v_rcp_f32 and
+    one Newton step instead of the compiler's 11-instruction division, and sqrt(x) (sphere.h:55, vec3.h:130,141,
+    material.h:73) for x in [2^-96, inf) without the general sequence's scaling and fix-up.  Proof by exhaustion on the
+    device: all 2^32 arguments of each, bit patterns compared (crt_selftest_exact_math)."""
+    r = crt.Renderer(0, 1)
+    try:
+        res = r.selftest_exact_math()
+    finally:
+        r.close()
+    for name, (bad, first, short) in res.items():
+        assert bad == 0, f"{name}: {bad} arguments differ, the smallest has bits {first:#010x}"
+    assert res["rcp"][2] == 2 * (200 * (1 << 23) + 1)  # 2 signs x (the 200 binades of [2^-100, 2^100) x 2^23 mantissas + 2^100 itself)
+    assert res["sqrt"][2] == res["rsqrt"][2] == (96 + 128) * (1 << 23)  # the binades of [2^-96, 2^128)
