@@ -264,7 +264,13 @@ int crt_upload_scene(crt_context* ctx, int32_t n, const float* center, const flo
         if (mat_type[i] == CRT_DIELECTRIC) {
             q[0] = mat_param[i];
             q[1] = float(1.0 / double(mat_param[i]));  // material.h:69 (1.0/refraction_index)
-            q[2] = q[3] = 0.0f;
+            // material.h:94-95: r0 = ((1 - ri) / (1 + ri))^2 for ri = ior (ray inside) and ri = 1/ior (ray outside), fp32
+            for (int side = 0; side < 2; ++side) {
+                const float ri = q[side];
+                float r0 = (1.0f - ri) / (1.0f + ri);
+                r0 = r0 * r0;
+                q[2 + side] = r0;
+            }
         } else {
             q[0] = mat_albedo[3 * i]; q[1] = mat_albedo[3 * i + 1]; q[2] = mat_albedo[3 * i + 2];
             q[3] = mat_type[i] == CRT_METAL ? (mat_param[i] < 1.0f ? mat_param[i] : 1.0f) : 0.0f;  // material.h:46

@@ -16,7 +16,7 @@
 //            bvh_node* stack[32] (helper_experimental.h:11-13).
 //  spheres : float4[2 * n]   { cx, cy, cz, radius }, { mx, my, mz, mat_id | type << 28 }
 //            (sphere.h:38-41: center ray origin, direction, radius, mat_ptr)
-//  mats    : float4[m]       lambertian/metal { r, g, b, fuzz }; dielectric { ior, 1/ior, -, - }
+//  mats    : float4[m]       lambertian/metal { r, g, b, fuzz }; dielectric { ior, 1/ior, r0(ior), r0(1/ior) }, r0(x) = ((1-x)/(1+x))^2 (material.h:94-95)
 //  sums    : int64[3 * W * H] un-normalised RGB sums in 2^-40 fixed point, row-major, RGB interleaved
 //            (the element order of helper.h:139-141's vec3 fb[W*H])
 #ifndef CRT_DEVICE_H

@@ -265,9 +265,13 @@ __device__ __forceinline__ sphere_rec load_sphere(const float4* spheres, int i) 
         lds_f4* p = (lds_f4*)(uint32_t)(uintptr_t)spheres;  // low half of a flat LDS address = LDS offset
         a = p[2 * i]; b = p[2 * i + 1];
     } else {
+        // (an unsigned 32-bit byte offset from the uniform base -- sphere indices are >= 0 and 32 n bytes < 4 GB, crt_upload_scene --
+        // is one shift and the scalar-base form of the load; the sign-extended 64-bit index cost three 64-bit instructions)
+        typedef __attribute__((address_space(1))) const char glb_char;
         typedef __attribute__((address_space(1))) const f4 glb_f4;
-        glb_f4* p = (glb_f4*)(uintptr_t)spheres;
-        a = p[2 * (size_t)i]; b = p[2 * (size_t)i + 1];
+        glb_char* base = (glb_char*)(uintptr_t)spheres;
+        const uint32_t off = (uint32_t)i << 5;
+        a = *(glb_f4*)(base + off); b = *(glb_f4*)(base + off + 16u);
     }
 #else
     a = b = f4{0, 0, 0, 0};  // host pass of the single-source compile: never runs
@@ -488,9 +492,10 @@ __device__ __forceinline__ hit_t closest_hit_bvh(const float4* pairs, const floa
     return best;
 }
 
-__device__ __forceinline__ float reflectance(float cosine, float ri) {  // material.h:92-97, powf(x,5) as multiplies
-    float r0 = (1.0f - ri) / (1.0f + ri);
-    r0 = r0 * r0;
+// material.h:92-97, powf(x,5) as multiplies.  r0 = ((1 - ri) / (1 + ri))^2 depends on the material and the side only: the
+// two values are in the material record (crt_upload_scene forms them with the same fp32 operations, correctly rounded on
+// the host as on the device), which saves the division here.
+__device__ __forceinline__ float reflectance(float cosine, float r0) {
     const float x = 1.0f - cosine;
     const float x2 = x * x;
     const float x4 = x2 * x2;
@@ -535,7 +540,7 @@ __device__ __forceinline__ bool shade(path_t& p, stream& rs, const sphere_rec& s
         const float cos_theta = fminf(dot(-ud, nrm), 1.0f);
         const float sin_theta = sqrt_(1.0f - cos_theta * cos_theta);
         bool do_reflect = ri * sin_theta > 1.0f;
-        if (!do_reflect) do_reflect = reflectance(cos_theta, ri) > (1.0f - rs.next_block().x);
+        if (!do_reflect) do_reflect = reflectance(cos_theta, front ? mrec.w : mrec.z) > (1.0f - rs.next_block().x);
         v3 dir;
         if (do_reflect) {
             dir = ud - (2.0f * dot(ud, nrm)) * nrm;
@@ -1191,6 +1196,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                             const float sin_theta = sqrt_(1.0f - scale * scale);
                             cannot = aux * sin_theta > 1.0f;
                             kind = cannot ? K_NONE : K_U;  // the draw is short-circuited away under TIR
+                            u1 = reflectance(scale, front ? mrec.w : mrec.z);  // (a K_U lane's block leaves u1 alone)
                         }
                     } else {
                         const v3 rad = sky(p);
@@ -1375,7 +1381,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         }
                     } else {
                         bool do_reflect = cannot;
-                        if (!do_reflect) do_reflect = reflectance(scale, aux) > (1.0f - u0);
+                        if (!do_reflect) do_reflect = u1 > (1.0f - u0);
                         if (do_reflect) {
                             dir = base - (2.0f * dot(base, nrm)) * nrm;
                         } else {  // refract, vec3.h:138-143
