@@ -191,13 +191,13 @@ class Renderer:
         return lib().crt_last_kernel_name(self._ctx).decode()
 
     def selftest_exact_math(self):
-        """{"rcp" | "sqrt" | "rsqrt": (arguments whose short sequence differs from the general one, smallest such
+        """{"rcp" | "sqrt" | "rsqrt" | "fixed": (arguments whose short sequence differs from the general one, smallest such
         argument's bits, arguments on the short sequence)} over all 2^32 arguments, on this context's GPU
         (crt_selftest_exact_math)."""
         import ctypes as C
-        out = (C.c_uint64 * 9)()
+        out = (C.c_uint64 * 12)()
         _check(lib().crt_selftest_exact_math(self._ctx, out), "crt_selftest_exact_math", self._ctx)
-        return {name: (out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i, name in enumerate(("rcp", "sqrt", "rsqrt"))}
+        return {name: (out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i, name in enumerate(("rcp", "sqrt", "rsqrt", "fixed"))}
 
     def set_count_stats(self, enable):
         _check(lib().crt_set_count_stats(self._ctx, int(enable)), "crt_set_count_stats", self._ctx)

@@ -214,20 +214,20 @@ int crt_set_arith(crt_context* ctx, int32_t arith) {
     return CRT_OK;
 }
 
-int crt_selftest_exact_math(crt_context* ctx, uint64_t* out9) {
+int crt_selftest_exact_math(crt_context* ctx, uint64_t* out12) {
     if (!ctx) return CRT_ERR_INVALID_ARGUMENT;
-    if (!out9) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_selftest_exact_math: out9 is NULL");
+    if (!out12) return fail(ctx, CRT_ERR_INVALID_ARGUMENT, "crt_selftest_exact_math: out12 is NULL");
     CRT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long* d = nullptr;
-    const unsigned long long init[9] = {0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull};
-    unsigned long long res[9];
+    const unsigned long long init[12] = {0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull, 0ull, ~0ull, 0ull};
+    unsigned long long res[12];
     CRT_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof init));
     hipError_t e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = crt_launch_math_selftest(d, nullptr);
     if (e == hipSuccess) e = hipMemcpy(res, d, sizeof res, hipMemcpyDeviceToHost);  // waits for the kernel
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, CRT_ERR_HIP, std::string("crt_selftest_exact_math: ") + hipGetErrorString(e));
-    for (int i = 0; i < 9; ++i) out9[i] = res[i];
+    for (int i = 0; i < 12; ++i) out12[i] = res[i];
     return CRT_OK;
 }
 

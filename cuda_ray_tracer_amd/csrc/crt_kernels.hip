@@ -583,6 +583,31 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 __device__ __forceinline__ unsigned long long to_fixed(float r) {
     return (unsigned long long)(long long)(fminf(r, 4096.0f) * 1099511627776.0f);  // 2^40; NaN -> 4096
 }
+// The same conversion for a radiance that is not negative (every radiance of a scene with non-negative albedos): the
+// two halves of the integer by one floor and one exact fma -- v = hi 2^32 + lo with hi = floor(v 2^-32), and
+// v - hi 2^32 < 2^32 keeps v's own low bits, which the unsigned conversion truncates -- 5 instructions where the
+// compiler's signed float -> int64 sequence takes 11 (absolute value, and the sign put back by two xors and a 64-bit
+// subtraction).  PROVEN equal to to_fixed() for every one of the 2^31 + 1 arguments it accepts (crt_selftest_exact_math).
+__device__ __forceinline__ float fixed_scaled(float r) { return fminf(r, 4096.0f) * 1099511627776.0f; }
+__device__ __forceinline__ bool fixed_plain(float v) { return v >= 0.0f; }  // v = fixed_scaled(r): never NaN
+__device__ __forceinline__ unsigned long long fixed_short(float v) {
+    const float hf = floorf(v * 2.3283064365386963e-10f);  // 2^-32: exact scaling
+    const uint32_t lo = (uint32_t)__builtin_fmaf(hf, -4294967296.0f, v);
+    return ((unsigned long long)(uint32_t)hf << 32) | lo;
+}
+// the three channels of one sample: the short conversion, the general one when some lane of the wave holds a negative one
+__device__ __forceinline__ void to_fixed3(v3 rad, unsigned long long& fx, unsigned long long& fy, unsigned long long& fz) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float vx = fixed_scaled(rad.x), vy = fixed_scaled(rad.y), vz = fixed_scaled(rad.z);
+    fx = fixed_short(vx); fy = fixed_short(vy); fz = fixed_short(vz);
+    const bool plain = fixed_plain(fminf(fminf(vx, vy), vz));
+    if (__builtin_expect(__ballot(!plain) != 0, 0)) {
+        if (!plain) { fx = to_fixed(rad.x); fy = to_fixed(rad.y); fz = to_fixed(rad.z); }
+    }
+#else
+    fx = to_fixed(rad.x); fy = to_fixed(rad.y); fz = to_fixed(rad.z);  // host pass of the single-source compile: never runs
+#endif
+}
 
 // The camera vectors of the kernel argument, read by scalar loads AT THE POINT OF USE (a new path's primary ray).  Read
 // through `a.cam`, the compiler loads the 18 floats once per kernel, holds them in scalar registers across the whole
@@ -1202,7 +1227,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const v3 rad = sky(p);
                         // (explicit address spaces: otherwise the two branches merge into flat atomics on a
                         // selected pointer)
-                        const unsigned long long fx = to_fixed(rad.x), fy = to_fixed(rad.y), fz = to_fixed(rad.z);
+                        unsigned long long fx, fy, fz;
+                        to_fixed3(rad, fx, fy, fz);
 #if defined(__HIP_DEVICE_COMPILE__)
                         if (PERSIST) wave_sync();  // the epoch may have been advanced by lanes that took a new unit while this one traced
                         if (PERSIST && (slot >> 6) != ust_ld(ust, U_EPOCH)) {
@@ -1707,6 +1733,7 @@ hipError_t launch_block(const crt_render_args& a, int block, int grid, size_t ld
 __global__ __launch_bounds__(256) void math_selftest_kernel(unsigned long long* out) {
     const unsigned long long n_threads = (unsigned long long)gridDim.x * blockDim.x;
     unsigned long long bad[3] = {0, 0, 0}, plain[3] = {0, 0, 0}, first[3] = {~0ull, ~0ull, ~0ull};
+    unsigned long long fbad = 0, fplain = 0, ffirst = ~0ull;  // function 3: the fixed-point conversion of a radiance
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += n_threads) {
         const float x = __uint_as_float((uint32_t)i);
         const float want[3] = {1.0f / x, sqrtf(x), 1.0f / sqrtf(x)};
@@ -1718,7 +1745,15 @@ __global__ __launch_bounds__(256) void math_selftest_kernel(unsigned long long* 
             if (!same) { ++bad[f]; if (i < first[f]) first[f] = i; }
             if (is_plain[f]) ++plain[f];
         }
+        // (a radiance of -inf or below -2^23 overflows the reference conversion's int64: undefined there, not compared)
+        const float v = fixed_scaled(x);
+        if (fixed_plain(v)) {
+            ++fplain;
+            if (fixed_short(v) != to_fixed(x)) { ++fbad; if (i < ffirst) ffirst = i; }
+        }
     }
+    if (fbad) { atomicAdd(&out[9], fbad); atomicMin(&out[10], ffirst); }
+    atomicAdd(&out[11], fplain);
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         if (bad[f]) { atomicAdd(&out[3 * f], bad[f]); atomicMin(&out[3 * f + 1], first[f]); }
@@ -1743,8 +1778,8 @@ hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& 
     hipLaunchKernelGGL(sum_frames_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, dst, src, count);
     return hipGetLastError();
 }
-hipError_t crt_launch_math_selftest(unsigned long long* out9, hipStream_t stream) {
-    hipLaunchKernelGGL(math_selftest_kernel, dim3(256 * 16), dim3(256), 0, stream, out9);
+hipError_t crt_launch_math_selftest(unsigned long long* out12, hipStream_t stream) {
+    hipLaunchKernelGGL(math_selftest_kernel, dim3(256 * 16), dim3(256), 0, stream, out12);
     return hipGetLastError();
 }
 #define crt_launch_render_tu crt_launch_render

@@ -23,7 +23,7 @@ hipError_t crt_launch_sum_frames(unsigned long long* dst, const crt_frame_list& 
 hipError_t crt_static_scratch(int device, unsigned long long** out);
 hipError_t crt_launch_resolve(const void* sums, float* fb, size_t count, int spp, hipStream_t stream);
 // out9 (device; {0, ~0, 0} x 3 on entry): for rcp_, sqrt_, rsqrt_ {arguments that differ from the general sequence, smallest such, arguments on the short one}
-hipError_t crt_launch_math_selftest(unsigned long long* out9, hipStream_t stream);
+hipError_t crt_launch_math_selftest(unsigned long long* out12, hipStream_t stream);
 hipError_t crt_launch_trace_samples(const crt_render_args& a, int world, int count, const int* px, const int* py,
                                     const int* samples, float* ray7, float* rgb, int* segments, hipStream_t stream);
 

@@ -239,11 +239,14 @@ const char* crt_build_id(void);
  * [2^-100, 2^100] for 1/x, x in [2^-96, inf) for the root -- the kernels use short sequences (v_rcp_f32 + one Newton
  * step, 3 instructions for the general division's 11; v_sqrt_f32 + the two one-ulp neighbours tried by their
  * residuals, 9 for 16) and the general ones for the rest.  This call proves on ctx's GPU that the results are the
- * same: it evaluates both forms of all three functions for EVERY one of the 2^32 arguments.  out9 = for 1/x, sqrt(x),
- * 1/sqrt(x) in turn: {number of arguments whose results differ as bit patterns (two NaNs count as equal) -- must be 0,
- * the smallest such argument's bits (~0 if none), number of arguments on the short sequence}.
- * No counterpart in the reference.  ~1 s. */
-int crt_selftest_exact_math(crt_context* ctx, uint64_t* out9);
+ * same: it evaluates both forms of all three functions for EVERY one of the 2^32 arguments.  The fourth function is the
+ * conversion of a sample's radiance to the frame's 2^-40 fixed point (render_with_cuda.h:128-165 accumulates floats;
+ * DESIGN.md "Accumulation contract"): for a radiance that is not negative the kernels split the integer with one floor
+ * and one exact fma instead of the compiler's signed float -> int64 sequence; every such argument is compared.
+ * out12 = for 1/x, sqrt(x), 1/sqrt(x), fixed(x) in turn: {number of arguments whose results differ as bit patterns
+ * (two NaNs count as equal) -- must be 0, the smallest such argument's bits (~0 if none), number of arguments on the
+ * short sequence}.  No counterpart in the reference.  ~2 s. */
+int crt_selftest_exact_math(crt_context* ctx, uint64_t* out12);
 
 /* Debug/parity: primary ray (7 floats), radiance (3 floats) and number of closest-hit
  * queries of single (pixel, sample) paths, computed by the same device functions as the

@@ -617,3 +617,5 @@ def test_short_reciprocal_and_root_are_the_general_ones_for_every_argument(crt):
         assert bad == 0, f"{name}: {bad} arguments differ, the smallest has bits {first:#010x}"
     assert res["rcp"][2] == 2 * (200 * (1 << 23) + 1)  # 2 signs x (the 200 binades of [2^-100, 2^100) x 2^23 mantissas + 2^100 itself)
     assert res["sqrt"][2] == res["rsqrt"][2] == (96 + 128) * (1 << 23)  # the binades of [2^-96, 2^128)
+    # the radiance -> 2^-40 fixed point conversion: +0 ... +inf, -0 and the NaNs (which fminf turns into 4096)
+    assert res["fixed"][2] == (0x7F800000 + 1) + 1 + 2 * ((1 << 23) - 1)
