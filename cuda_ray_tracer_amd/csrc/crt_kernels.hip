@@ -1180,12 +1180,23 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             const bool shading = (k == 0u) & !finished;
             enum { K_NONE = 0, K_VEC = 1, K_U = 2, K_CAM = 3, K_DISK = 4 };
             int kind = K_NONE, type = -1;
-            v3 nrm = mk(0, 0, 0), base = mk(0, 0, 0);
-            float scale = 0.0f, aux = 0.0f;          // VEC: fuzz / -, dielectric: cos_theta / ri
-            float u0 = 0, u1 = 0, u2 = 0, u3 = 0;    // VEC: p.xyz, lensq; K_U: u; CAM: x_off, y_off, time
-            bool cannot = false;
-            int px = 0, py = 0;
-            float dx = 0.0f, dy = 0.0f;
+            // The values below are written in part 1 or in the block loop by exactly the lanes that read them in part 3
+            // (by material type / kind of block), so they need no initial value.  Left uninitialised they save 17 v_mov
+            // at the phase's merge points (1447 -> 1409 vector instructions in the code): the tolerance build gains
+            // 1.4 % (64.5 -> 63.6 ms), the exact build -- 80 instead of 78 VGPRs, another allocation -- loses 0.15 %
+            // (alternating A/B), so only the tolerance build does it.
+#if CRT_FAST
+#define CRT_INIT(v)
+#else
+#define CRT_INIT(v) = v
+#endif
+            v3 nrm CRT_INIT(mk(0, 0, 0)), base CRT_INIT(mk(0, 0, 0));
+            float scale CRT_INIT(0.0f), aux CRT_INIT(0.0f);  // VEC: fuzz / -, dielectric: cos_theta / ri
+            float u0 CRT_INIT(0.0f), u1 CRT_INIT(0.0f), u2 CRT_INIT(0.0f), u3 CRT_INIT(0.0f);  // VEC: p.xyz, lensq; K_U: u (u1: the Schlick reflectance); CAM: x_off, y_off, time
+            bool cannot CRT_INIT(false);
+            int px CRT_INIT(0), py CRT_INIT(0);
+            float dx CRT_INIT(0.0f), dy CRT_INIT(0.0f);
+#undef CRT_INIT
             if (shading) {
                 // One Philox loop serves every lane of the phase, whatever it needs the block for:
                 //   K_VEC  an attempt of random_unit_vector (lambertian, metal)     vec3.h:145-152
