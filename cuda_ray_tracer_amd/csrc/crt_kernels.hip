@@ -1159,13 +1159,12 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 // ONE sphere per lane and phase: a hit sibling (2% of the leaf visits) is the lane's next
                 // leaf, tested in the next sphere phase, instead of a second test that the whole wave
                 // would step through for the one lane that needs it
-                if (pending & 1u) { k ^= 1u; pending &= ~1u; }
-                else if (NL == 1u) { k = 0u; }  // the root was the only leaf
-                else {
-                    const int up = __builtin_ctz(pending);
-                    k = (k >> up) ^ 1u;
-                    pending = (pending >> up) ^ 1u;
-                }
+                // -- which is the ordinary pop: bit 0 of `pending` set means "my sibling, zero levels up", and the pop
+                // formula with up = 0 gives k ^ 1 and clears the bit; a root that is the only leaf (k = 1 under the
+                // sentinel bit 0) pops to k = 0 the same way.  One formula, no case distinction (6 vector instructions less).
+                const uint32_t up = (uint32_t)__builtin_ctz(pending);  // the sentinel keeps pending != 0
+                k = (k >> up) ^ 1u;
+                pending = (pending >> up) ^ 1u;
             }
             CRT_LAP(2);
         }
