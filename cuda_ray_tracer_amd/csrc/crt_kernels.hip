@@ -1149,10 +1149,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             if (ROLE == 1) wait_polls = 0;
             if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
-                int2 tg;
-                if (IN_LDS) tg = ws.leaf_tags[k >> 1];
-                else { const float4 q3 = pairs[4 * (k >> 1) + 3]; tg = make_int2(__float_as_int(q3.x), __float_as_int(q3.y)); }
-                const int cand = (k & 1u) ? tg.y : tg.x;
+                // (in LDS the tag pairs of the leaf parents form one int array indexed by the leaf's own node index)
+                int cand;
+                if (IN_LDS) cand = ((const int*)ws.leaf_tags)[k];
+                else { const float4 q3 = pairs[4 * (k >> 1) + 3]; cand = (k & 1u) ? __float_as_int(q3.y) : __float_as_int(q3.x); }
                 const float root = sphere_root(load_sphere<IN_LDS && CRT_SCHED_SPHERES_IN_LDS>(spheres, cand), p.r, ray_a, tmin, best_t);
                 if (COUNT) n_tests += 1;
                 if (root > 0.0f) { best_t = root; best_obj = cand; }
