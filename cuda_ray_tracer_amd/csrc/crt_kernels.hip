@@ -1145,7 +1145,8 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                 if (__popcll(m_walk) <= leave_at) break;
             }
             CRT_LAP(1);
-        } else {
+        }
+        if (ph == ST_LEAF) {
             if (ROLE == 1) wait_polls = 0;
             if (k >= NL) {
                 // sphere tags of the leaf pair that holds node k (helper_experimental.h:16-31: left, then right)
