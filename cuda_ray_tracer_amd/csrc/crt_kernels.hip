@@ -1004,6 +1004,9 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       // changes only k, `pending` and the best hit, so the rest of the lane state stays in place in
       // its registers across it (no copies at the loop's merge points).
       int phase = -1;
+      // (`finished` only changes in the shade phase: its lane mask is formed once per outer iteration, and the scheduler's
+      // ballot below is a plain compare and a scalar and-not instead of a materialised boolean)
+      const unsigned long long m_fin = (ROLE == 1) ? 0ull : __ballot(finished);
       for (;;) {
         if (ROLE == 1) {
             // collect: a lane whose ray is out reads its mailbox word
@@ -1035,7 +1038,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         }
         const unsigned long long m_run = __ballot((k - 1u) < (NL - 1u));
         const unsigned long long m_leaf = __ballot(k >= NL);
-        const unsigned long long m_shade = __ballot((k == 0u) & !finished);
+        const unsigned long long m_shade = (ROLE == 1) ? __ballot((k == 0u) & !finished) : (__builtin_amdgcn_uicmp(k, 0u, 32 /* eq */) & ~m_fin);  // (an owner's watchdog may set `finished` inside this loop)
         const int n_run = __popcll(m_run), n_leaf = __popcll(m_leaf), n_shade = __popcll(m_shade);
         const int alive = n_run + n_leaf + n_shade;
         if (alive == 0) break;
