@@ -1007,6 +1007,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
       // (`finished` only changes in the shade phase: its lane mask is formed once per outer iteration, and the scheduler's
       // ballot below is a plain compare and a scalar and-not instead of a materialised boolean)
       const unsigned long long m_fin = (ROLE == 1) ? 0ull : __ballot(finished);
+#if CRT_FAST
+      // (likewise the lanes with a non-finite reciprocal, set where a segment begins -- in the tolerance build only: 63.2 ->
+      // 62.5 ms there, 72.4 -> 72.8 ms in the exact build, whose registers fall differently; alternating A/B)
+      const unsigned long long m_exact = __ballot(exact);
+#endif
       for (;;) {
         if (ROLE == 1) {
             // collect: a lane whose ray is out reads its mailbox word
@@ -1070,7 +1075,11 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             // Rays with a non-finite reciprocal (a zero or denormal direction component: rare) take the literal
             // comparisons of aabb.h:48-62 on the HBM records, HERE, until they reach a leaf or finish -- so the hot
             // loop below carries no branch for them (6 scalar instructions per step less).
+#if CRT_FAST
+            if ((m_exact & m_run) != 0) {
+#else
             if (__ballot(exact && ((k - 1u) < (NL - 1u))) != 0) {
+#endif
                 while (exact && ((k - 1u) < (NL - 1u))) {
                     if (COUNT) n_pairs += 1;
                     const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
