@@ -1,0 +1,17 @@
+#!/bin/bash
+# check_vgprs.sh <object> : the persistent BVH kernels (render_kernel<1, *, false, 768, 2>: two 12-wave workgroups per CU,
+# 6 waves per SIMD) must stay within 80 VGPRs and without scratch -- at 81 the second workgroup of a CU is never resident
+# and the kernel runs 30-45 % slower (it happened twice in round 3: a harmless-looking source change moved the tolerance
+# build to 85 registers, 62 -> 93 ms).  Run by the Makefile after each kernel object is built; fails the build.
+set -e
+obj=$1
+LLVM=/opt/rocm/lib/llvm/bin
+tmp=$(mktemp -d)
+trap 'rm -rf $tmp' EXIT
+$LLVM/llvm-objcopy --dump-section .hip_fatbin=$tmp/fb.bin $obj
+$LLVM/clang-offload-bundler --unbundle --type=o --input=$tmp/fb.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/k.co
+$LLVM/llvm-readelf --notes $tmp/k.co | awk '
+  /\.name:/ { name = $2 }
+  /\.private_segment_fixed_size:/ { scratch = $2 }
+  /\.vgpr_count:/ { if (name ~ /render_kernelILi1ELb[01]ELb0ELi768ELi2E/) { n++; printf "%s: %d VGPRs, %d B scratch\n", name, $2, scratch; if ($2 > 80 || scratch > 0) bad = 1 } }
+  END { if (n < 2) { print "check_vgprs: persistent kernels not found in " FILENAME; exit 1 } if (bad) { print "check_vgprs: over the 6-waves-per-SIMD budget (80 VGPRs, no scratch)"; exit 1 } }'

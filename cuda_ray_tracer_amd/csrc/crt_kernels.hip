@@ -32,6 +32,9 @@
 // Where rays with a non-finite reciprocal take their literal walk: 1 = where a lane enters the walking state (start of a
 // segment, after a sphere test), 0 = in front of the hot walking loop.  Measured per build (alternating A/B): the exact
 // build gains 0.36 % with 1 (71.97 vs 72.23 ms), the tolerance build loses 0.6 % (62.8 vs 62.4 ms).
+#ifndef CRT_VARIANT
+#define CRT_VARIANT 0
+#endif
 #ifndef CRT_LITERAL_AT_ENTRY
 #define CRT_LITERAL_AT_ENTRY (!CRT_FAST)
 #endif
@@ -1003,6 +1006,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
         const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // per-wave records: start, queue empty, exit
         if (PERSIST && wid < 8192u) a.counters[CRT_TIMELINE_BASE + 3 * wid] = t;
     }
+#if CRT_LITERAL_AT_ENTRY
     // Rays with a non-finite reciprocal (a zero or denormal direction component: rare) take the literal comparisons of
     // aabb.h:48-62 on the HBM records until they reach a leaf or finish.
     auto walk_literal = [&]() {
@@ -1016,6 +1020,7 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             successor(k, pending, hitL, hitR);
         }
     };
+#endif
 #define CRT_LAP(i) do { if (timing) { const long long t_ = (long long)__builtin_readcyclecounter(); tc[i] += (unsigned long long)(t_ - t_mark); t_mark = t_; } } while (0)
 
     for (;;) {
@@ -1096,10 +1101,23 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
             // loop below carries no branch for them (6 scalar instructions per step less).
 #if CRT_LITERAL_AT_ENTRY
             // (they walk where they enter the walking state: at the start of a segment and after a sphere test)
-#elif CRT_FAST
-            if ((m_exact & m_run) != 0) walk_literal();
 #else
-            if (__ballot(exact && ((k - 1u) < (NL - 1u))) != 0) walk_literal();
+            // in front of the hot loop, which then carries no branch for them
+#if CRT_FAST
+            if ((m_exact & m_run) != 0) {
+#else
+            if (__ballot(exact && ((k - 1u) < (NL - 1u))) != 0) {
+#endif
+                while (exact && ((k - 1u) < (NL - 1u))) {
+                    if (COUNT) n_pairs += 1;
+                    const float4 q0 = pairs[4 * k], q1 = pairs[4 * k + 1], q2 = pairs[4 * k + 2], q3 = pairs[4 * k + 3];
+                    bool hitL = slab(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.r.o, inv, tmin, best_t);
+                    bool hitR = slab(q0.z, q0.w, q1.z, q1.w, q2.z, q2.w, p.r.o, inv, tmin, best_t);
+                    hitL = hitL & (__float_as_int(q3.x) != CRT_TAG_EMPTY);
+                    hitR = hitR & (__float_as_int(q3.y) != CRT_TAG_EMPTY);
+                    successor(k, pending, hitL, hitR);
+                }
+            }
 #endif
             // (the set of walking lanes is carried round the loop as a lane MASK in scalar registers and turned back
             // into the branch condition for free; carried as a boolean it cost three scalar mask merges per step)
@@ -1442,7 +1460,13 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const v3 ruv = rsqrt_(u3) * mk(u0, u1, u2);
                         dir = base + scale * ruv;
                         if (type == 0) {  // vec3.h:62-66 near_zero (double threshold)
+#if CRT_VARIANT == 6
+                            // (a float is below the double 1e-8 exactly when it is below the smallest float above 1e-8)
+                            const float nz = __uint_as_float(0x322BCC78u);  // the float next above 1e-8 (which lies between 0x322BCC77 and it)
+                            if ((fabsf(dir.x) < nz) && (fabsf(dir.y) < nz) && (fabsf(dir.z) < nz)) dir = nrm;
+#else
                             if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = nrm;
+#endif
                         } else {
                             absorbed = !(dot(dir, nrm) > 0.0f);  // material.h:54
                         }
@@ -1485,9 +1509,19 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         inv = rcp3(p.r.d);  // aabb.h:48
                         exact = !finite3(inv);
                         if (IN_LDS) {
+#if CRT_VARIANT == 6
+                            // the sign BIT picks the plane array (NL is a power of two: the array index is an or).  -0 and a
+                            // negative NaN differ from "d < 0", but their reciprocal is not finite: such a ray takes the
+                            // literal walk and never uses the offsets.
+                            const uint32_t n16 = NL << 4;
+                            offx = (uint32_t)(__float_as_int(p.r.d.x) >> 31) & n16;
+                            offy = ((uint32_t)(__float_as_int(p.r.d.y) >> 31) & n16) | (2u * n16);
+                            offz = ((uint32_t)(__float_as_int(p.r.d.z) >> 31) & n16) | (4u * n16);
+#else
                             offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
                             offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
                             offz = (p.r.d.z < 0.0f ? 5u * NL : 4u * NL) << 4;
+#endif
                         }
 #if CRT_LITERAL_AT_ENTRY
                         if (ROLE != 1) walk_literal();
