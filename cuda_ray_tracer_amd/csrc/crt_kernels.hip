@@ -32,9 +32,6 @@
 // Where rays with a non-finite reciprocal take their literal walk: 1 = where a lane enters the walking state (start of a
 // segment, after a sphere test), 0 = in front of the hot walking loop.  Measured per build (alternating A/B): the exact
 // build gains 0.36 % with 1 (71.97 vs 72.23 ms), the tolerance build loses 0.6 % (62.8 vs 62.4 ms).
-#ifndef CRT_VARIANT
-#define CRT_VARIANT 0
-#endif
 #ifndef CRT_LITERAL_AT_ENTRY
 #define CRT_LITERAL_AT_ENTRY (!CRT_FAST)
 #endif
@@ -1460,13 +1457,10 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         const v3 ruv = rsqrt_(u3) * mk(u0, u1, u2);
                         dir = base + scale * ruv;
                         if (type == 0) {  // vec3.h:62-66 near_zero (double threshold)
-#if CRT_VARIANT == 6
-                            // (a float is below the double 1e-8 exactly when it is below the smallest float above 1e-8)
+                            // vec3.h:62-66 near_zero compares in double: a float is below the double 1e-8 exactly when it is below the
+                            // smallest float above it -- one fp32 compare per component instead of a conversion and an fp64 compare
                             const float nz = __uint_as_float(0x322BCC78u);  // the float next above 1e-8 (which lies between 0x322BCC77 and it)
                             if ((fabsf(dir.x) < nz) && (fabsf(dir.y) < nz) && (fabsf(dir.z) < nz)) dir = nrm;
-#else
-                            if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = nrm;
-#endif
                         } else {
                             absorbed = !(dot(dir, nrm) > 0.0f);  // material.h:54
                         }
@@ -1509,7 +1503,6 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                         inv = rcp3(p.r.d);  // aabb.h:48
                         exact = !finite3(inv);
                         if (IN_LDS) {
-#if CRT_VARIANT == 6
                             // the sign BIT picks the plane array (NL is a power of two: the array index is an or).  -0 and a
                             // negative NaN differ from "d < 0", but their reciprocal is not finite: such a ray takes the
                             // literal walk and never uses the offsets.
@@ -1517,11 +1510,6 @@ __device__ __forceinline__ void trace_bvh_scheduled(const crt_render_args& a, co
                             offx = (uint32_t)(__float_as_int(p.r.d.x) >> 31) & n16;
                             offy = ((uint32_t)(__float_as_int(p.r.d.y) >> 31) & n16) | (2u * n16);
                             offz = ((uint32_t)(__float_as_int(p.r.d.z) >> 31) & n16) | (4u * n16);
-#else
-                            offx = (p.r.d.x < 0.0f ? NL : 0u) << 4;
-                            offy = (p.r.d.y < 0.0f ? 3u * NL : 2u * NL) << 4;
-                            offz = (p.r.d.z < 0.0f ? 5u * NL : 4u * NL) << 4;
-#endif
                         }
 #if CRT_LITERAL_AT_ENTRY
                         if (ROLE != 1) walk_literal();
